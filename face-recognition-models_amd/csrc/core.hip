@@ -1,0 +1,32 @@
+// libfrx core: version, thread-local error text, device properties.
+#include "frx_common.h"
+#include <string.h>
+
+namespace frx {
+static thread_local char g_err[512] = "";
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+}  // namespace frx
+
+extern "C" int frx_version(void) { return 100; /* 0.1.0 */ }
+
+extern "C" const char* frx_last_error(void) { return frx::g_err; }
+
+extern "C" int frx_device_props(int device, int64_t props[8]) {
+  FRX_CHECK_ARG(props != nullptr, "props is NULL");
+  hipDeviceProp_t p;
+  FRX_HIP(hipGetDeviceProperties(&p, device));
+  props[0] = p.multiProcessorCount;
+  props[1] = p.clockRate;
+  props[2] = (int64_t)p.maxSharedMemoryPerMultiProcessor;
+  props[3] = p.warpSize;
+  props[4] = strstr(p.gcnArchName, "gfx950") != nullptr;
+  props[5] = (int64_t)(p.totalGlobalMem >> 20);
+  props[6] = p.memoryClockRate;
+  props[7] = p.memoryBusWidth;
+  return FRX_OK;
+}

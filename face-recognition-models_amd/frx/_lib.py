@@ -1,0 +1,80 @@
+"""ctypes loader for libfrx.so (include/frx.h).  The library is built in-tree by
+`make -C face-recognition-models_amd/csrc` (or __graft_entry__.build())."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libfrx.so")
+_lib = None
+
+
+class FrxError(RuntimeError):
+    pass
+
+
+class HeadDesc(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("N", C.c_int32), ("D", C.c_int32), ("C", C.c_int32),
+                ("s", C.c_float), ("m", C.c_float), ("momentum", C.c_float), ("lamb", C.c_float)]
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+_P = C.c_void_p
+_SIGS = {
+    "frx_version": (C.c_int, []),
+    "frx_last_error": (C.c_char_p, []),
+    "frx_device_props": (C.c_int, [C.c_int, C.POINTER(C.c_int64)]),
+    "frx_head_workspace_bytes": (C.c_size_t, [C.POINTER(HeadDesc)]),
+    "frx_head_fwd_cos": (C.c_int, [C.c_int, _P, C.POINTER(HeadDesc), _P, _P, _P, _P, C.c_size_t, _P]),
+    "frx_head_fwd_loss": (C.c_int, [C.c_int, _P, C.POINTER(HeadDesc), _P, _P, _P, C.c_int64, _P, C.c_size_t,
+                                    _P, _P, _P, _P, _P, _P]),
+    "frx_head_fwd": (C.c_int, [C.c_int, _P, C.POINTER(HeadDesc), _P, _P, _P, _P, _P, C.c_size_t,
+                               _P, _P, _P, _P, _P, _P]),
+    "frx_head_bwd": (C.c_int, [C.c_int, _P, C.POINTER(HeadDesc), _P, _P, _P, _P, _P, _P, C.c_size_t,
+                               _P, _P, C.c_int]),
+    "frx_pair_cosine": (C.c_int, [C.c_int, _P, _P, _P, C.c_int64, C.c_int32, _P]),
+    "frx_threshold_count": (C.c_int, [C.c_int, _P, _P, _P, C.c_int64, C.c_float, _P]),
+}
+
+
+def load_library(path: str | None = None):
+    """Load libfrx.so and bind every symbol include/frx.h declares.  Raises FrxError
+    (never falls back) when the library or a symbol is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or _LIB_PATH
+    if not os.path.exists(p):
+        raise FrxError(f"native library not built: {p} is missing -- run "
+                       f"`make -C face-recognition-models_amd/csrc` or __graft_entry__.build()")
+    try:
+        lib_ = C.CDLL(p)
+    except OSError as e:  # e.g. ROCm runtime absent
+        raise FrxError(f"cannot load {p}: {e}") from e
+    for name, (res, args) in _SIGS.items():
+        try:
+            fn = getattr(lib_, name)
+        except AttributeError as e:
+            raise FrxError(f"{p} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib_
+    return _lib
+
+
+def lib():
+    return load_library()
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().frx_last_error().decode("utf-8", "replace")
+        raise FrxError(f"{what} failed (status {rc}): {msg}")
+
+
+def exported_symbols():
+    return list(_SIGS)
