@@ -1,0 +1,466 @@
+// Train-mode BatchNorm pieces that cannot live inside a conv kernel, the residual merge,
+// the stem max-pool and the average pool -- all HBM-bound, 16-byte vectorised, NHWC.
+// Reference call sites: nn.BatchNorm2d x53, nn.ReLU x49, residual add x16, MaxPool2d,
+// AdaptiveAvgPool2d of the torchvision ResNet-50 built in main_code/utils/backbones.py:16-18.
+#include "conv_kernels.h"
+
+namespace frx {
+
+template <typename T> struct Vec16 {
+  uint4 raw;
+  static constexpr int N = 16 / sizeof(T);
+  __device__ __forceinline__ float get(int j) const {
+    if constexpr (sizeof(T) == 4) return reinterpret_cast<const float*>(&raw)[j];
+    else return (float)reinterpret_cast<const bf16_t*>(&raw)[j];
+  }
+  __device__ __forceinline__ void set(int j, float v) {
+    if constexpr (sizeof(T) == 4) reinterpret_cast<float*>(&raw)[j] = v;
+    else reinterpret_cast<bf16_t*>(&raw)[j] = (bf16_t)v;
+  }
+};
+
+// ---------------------------------------------------------------- BN forward statistics
+// partial [rows][2][C] (sum, sum of squares from the conv epilogue) -> batch mean / biased var,
+// scale = gamma*invstd, shift = beta - mean*scale, running stats (momentum 0.1, unbiased var).
+__global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ partial, int rows, int C,
+                                                     double count, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps, float momentum,
+                                                     float* __restrict__ rmean, float* __restrict__ rvar,
+                                                     float* __restrict__ mean_o, float* __restrict__ invstd_o,
+                                                     float* __restrict__ scale_o, float* __restrict__ shift_o) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, q = 0.0;
+  for (int r = 0; r < rows; ++r) {
+    s += (double)partial[((long)r * 2 + 0) * C + c];
+    q += (double)partial[((long)r * 2 + 1) * C + c];
+  }
+  const double mean = s / count;
+  double var = q / count - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+  const float sc = gamma[c] * invstd;
+  mean_o[c] = (float)mean;
+  invstd_o[c] = invstd;
+  scale_o[c] = sc;
+  shift_o[c] = beta[c] - (float)mean * sc;
+  if (rmean) {
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_bn_eval_affine(int C, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta,
+                                                        const float* __restrict__ rmean,
+                                                        const float* __restrict__ rvar, float eps,
+                                                        float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float sc = gamma[c] / sqrtf(rvar[c] + eps);
+  scale[c] = sc;
+  shift[c] = beta[c] - rmean[c] * sc;
+}
+
+// ---------------------------------------------------------------- residual merge (forward)
+// out = relu(s3*y3 + b3 + idn)            idn = block input, or sd*yd + bd for a downsample branch
+template <typename T>
+__global__ __launch_bounds__(256) void k_merge_fwd(long nvec, int C, const T* __restrict__ y3,
+                                                   const float* __restrict__ s3, const float* __restrict__ b3,
+                                                   const T* __restrict__ idn, const float* __restrict__ sd,
+                                                   const float* __restrict__ bd, T* __restrict__ out) {
+  constexpr int V = Vec16<T>::N;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+    const int c = (int)((i * V) % C);
+    Vec16<T> a, b, o;
+    a.raw = reinterpret_cast<const uint4*>(y3)[i];
+    b.raw = reinterpret_cast<const uint4*>(idn)[i];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      float id = b.get(j);
+      if (sd) id = fmaf(id, sd[c + j], bd[c + j]);
+      o.set(j, fmaxf(fmaf(a.get(j), s3[c + j], b3[c + j]) + id, 0.f));
+    }
+    reinterpret_cast<uint4*>(out)[i] = o.raw;
+  }
+}
+
+// ---------------------------------------------------------------- BN backward
+// dz = g * mask;  mask = (out > 0) when `out` is given (merge ReLU), else (scale*y+shift > 0) when
+// relu, else 1.  Accumulates per channel  sum(dz)  and  sum(dz * xhat),  xhat = (y-mean)*invstd.
+// Block b handles rows b, b+gridDim, ...; thread owns one 16-byte channel group.
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_bwd_reduce(long rows, int C, const T* __restrict__ g,
+                                                       const T* __restrict__ y, const T* __restrict__ out,
+                                                       const float* __restrict__ scale,
+                                                       const float* __restrict__ shift, int relu,
+                                                       const float* __restrict__ mean,
+                                                       const float* __restrict__ invstd, T* __restrict__ dz_out,
+                                                       float* __restrict__ partial) {
+  constexpr int V = Vec16<T>::N;
+  __shared__ float red[2][256][V + 1];
+  const int groups = C / V;                         // channel groups per row
+  const int gpb = groups < 256 ? groups : 256;      // groups handled per pass
+  const int rpp = 256 / gpb;                        // rows per pass
+  const int tg = threadIdx.x % gpb, trow = threadIdx.x / gpb;
+  for (int g0 = 0; g0 < groups; g0 += gpb) {
+    const int grp = g0 + tg;
+    const int c = grp * V;
+    float s1[V], s2[V], mu[V], is[V], sc[V], sh[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      s1[j] = 0.f; s2[j] = 0.f;
+      mu[j] = mean[c + j]; is[j] = invstd[c + j];
+      sc[j] = scale ? scale[c + j] : 1.f; sh[j] = shift ? shift[c + j] : 0.f;
+    }
+    if (trow < rpp) {
+      for (long r = (long)blockIdx.x * rpp + trow; r < rows; r += (long)gridDim.x * rpp) {
+        const long i = r * groups + grp;
+        Vec16<T> vg, vy, vo, vz;
+        vg.raw = reinterpret_cast<const uint4*>(g)[i];
+        vy.raw = reinterpret_cast<const uint4*>(y)[i];
+        if (out) vo.raw = reinterpret_cast<const uint4*>(out)[i];
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          const float yy = vy.get(j);
+          bool on = true;
+          if (out) on = vo.get(j) > 0.f;
+          else if (relu) on = fmaf(yy, sc[j], sh[j]) > 0.f;
+          const float dz = on ? vg.get(j) : 0.f;
+          s1[j] += dz;
+          s2[j] += dz * (yy - mu[j]) * is[j];
+          vz.set(j, dz);
+        }
+        if (dz_out) reinterpret_cast<uint4*>(dz_out)[i] = vz.raw;
+      }
+    }
+    // reduce over the rpp row-lanes that share a channel group
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < V; ++j) { red[0][threadIdx.x][j] = s1[j]; red[1][threadIdx.x][j] = s2[j]; }
+    __syncthreads();
+    if (threadIdx.x < gpb) {
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        float a = 0.f, b = 0.f;
+        for (int rr = 0; rr < rpp; ++rr) { a += red[0][rr * gpb + threadIdx.x][j]; b += red[1][rr * gpb + threadIdx.x][j]; }
+        partial[((long)blockIdx.x * 2 + 0) * C + c + j] = a;
+        partial[((long)blockIdx.x * 2 + 1) * C + c + j] = b;
+      }
+    }
+  }
+}
+
+// partial [nblk][2][C] -> dgamma += , dbeta += , coef[0]=gamma*invstd, coef[1]=sum(dz)/M, coef[2]=sum(dz*xhat)/M
+__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict__ partial, int nblk, int C,
+                                                         double count, const float* __restrict__ gamma,
+                                                         const float* __restrict__ invstd,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                         float* __restrict__ coef) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int r = 0; r < nblk; ++r) {
+    a += (double)partial[((long)r * 2 + 0) * C + c];
+    b += (double)partial[((long)r * 2 + 1) * C + c];
+  }
+  if (dbeta) dbeta[c] += (float)a;
+  if (dgamma) dgamma[c] += (float)b;
+  coef[c] = gamma[c] * invstd[c];
+  coef[C + c] = (float)(a / count);
+  coef[2 * C + c] = (float)(b / count);
+}
+
+// dy = k1 * (dz - c1 - xhat*c2);  dz = g*mask with the same mask rule as the reduce kernel
+template <typename T>
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(long nvec, int C, const T* __restrict__ g,
+                                                      const T* __restrict__ y, const T* __restrict__ out,
+                                                      const float* __restrict__ scale,
+                                                      const float* __restrict__ shift, int relu,
+                                                      const float* __restrict__ mean,
+                                                      const float* __restrict__ invstd,
+                                                      const float* __restrict__ coef, T* __restrict__ dy) {
+  constexpr int V = Vec16<T>::N;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
+    const int c = (int)((i * V) % C);
+    Vec16<T> vg, vy, vo, vd;
+    vg.raw = reinterpret_cast<const uint4*>(g)[i];
+    vy.raw = reinterpret_cast<const uint4*>(y)[i];
+    if (out) vo.raw = reinterpret_cast<const uint4*>(out)[i];
+#pragma unroll
+    for (int j = 0; j < V; ++j) {
+      const float yy = vy.get(j);
+      bool on = true;
+      if (out) on = vo.get(j) > 0.f;
+      else if (relu) on = fmaf(yy, scale[c + j], shift[c + j]) > 0.f;
+      const float dz = on ? vg.get(j) : 0.f;
+      const float xh = (yy - mean[c + j]) * invstd[c + j];
+      vd.set(j, coef[c + j] * (dz - coef[C + c + j] - xh * coef[2 * C + c + j]));
+    }
+    reinterpret_cast<uint4*>(dy)[i] = vd.raw;
+  }
+}
+
+// ---------------------------------------------------------------- stem max-pool 3x3 s2 p1
+// out = maxpool(relu(scale*y + shift)); argmax keeps the window position (kh*3+kw) of the first
+// maximum in scan order (torch's tie rule) for the backward gather.
+template <typename T>
+__global__ __launch_bounds__(256) void k_pool_fwd(int N, int H, int W, int C, const T* __restrict__ y,
+                                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                                  T* __restrict__ out, uint8_t* __restrict__ argmax) {
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long total = (long)N * Ho * Wo * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    long p = i / C;
+    const int ow = (int)(p % Wo); p /= Wo;
+    const int oh = (int)(p % Ho);
+    const int n = (int)(p / Ho);
+    const float sc = scale[c], sh = shift[c];
+    float best = -INFINITY;
+    int arg = 0;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int h = oh * 2 - 1 + kh, w = ow * 2 - 1 + kw;
+        if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+          float v = fmaxf(fmaf(load_as_float<T>(y, (((long)n * H + h) * W + w) * C + c), sc, sh), 0.f);
+          v = (float)(T)v;
+          if (v > best) { best = v; arg = kh * 3 + kw; }
+        }
+      }
+    out[i] = (T)best;
+    argmax[i] = (uint8_t)arg;
+  }
+}
+
+// gradient w.r.t. the post-ReLU stem activation: gather from the <=4 windows covering a pixel
+template <typename T>
+__global__ __launch_bounds__(256) void k_pool_bwd(int N, int H, int W, int C, const T* __restrict__ dout,
+                                                  const uint8_t* __restrict__ argmax, T* __restrict__ dpost) {
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const long total = (long)N * H * W * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    long p = i / C;
+    const int w = (int)(p % W); p /= W;
+    const int h = (int)(p % H);
+    const int n = (int)(p / H);
+    float acc = 0.f;
+    // windows oh with oh*2-1 <= h <= oh*2+1
+    for (int oh = (h >> 1); oh <= ((h + 1) >> 1); ++oh) {
+      if (oh >= Ho) continue;
+      const int kh = h - (oh * 2 - 1);
+      for (int ow = (w >> 1); ow <= ((w + 1) >> 1); ++ow) {
+        if (ow >= Wo) continue;
+        const int kw = w - (ow * 2 - 1);
+        const long o = (((long)n * Ho + oh) * Wo + ow) * C + c;
+        if (argmax[o] == kh * 3 + kw) acc += load_as_float<T>(dout, o);
+      }
+    }
+    dpost[i] = (T)acc;
+  }
+}
+
+// ---------------------------------------------------------------- average pool over HW
+template <typename T>
+__global__ __launch_bounds__(256) void k_avgpool_fwd(int N, int HW, int C, const T* __restrict__ x, T* __restrict__ out) {
+  const long total = (long)N * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long n = i / C;
+    float s = 0.f;
+    for (int p = 0; p < HW; ++p) s += load_as_float<T>(x, (n * HW + p) * C + c);
+    out[i] = (T)(s / (float)HW);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_avgpool_bwd(int N, int HW, int C, const T* __restrict__ dpool, T* __restrict__ dx) {
+  const long total = (long)N * HW * C;
+  const float inv = 1.f / (float)HW;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long n = i / ((long)HW * C);
+    dx[i] = (T)(load_as_float<T>(dpool, n * C + c) * inv);
+  }
+}
+
+static inline int ew_grid(long work_items) {
+  long b = (work_items + 255) / 256;
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace frx
+using namespace frx;
+
+#define FRX_DT_CHECK(dt) FRX_CHECK_ARG((dt) == FRX_F32 || (dt) == FRX_BF16, "unsupported dtype %d", (dt))
+#define FRX_VEC(dt) ((dt) == FRX_BF16 ? 8 : 4)
+
+extern "C" int frx_bn_finalize(int device, frx_stream_t stream, const float* partial, int rows, int C,
+                               int64_t count, const float* gamma, const float* beta, float eps, float momentum,
+                               float* running_mean, float* running_var, float* mean, float* invstd,
+                               float* scale, float* shift) {
+  FRX_CHECK_ARG(partial && gamma && beta && mean && invstd && scale && shift, "bn_finalize: NULL pointer");
+  FRX_CHECK_ARG(rows > 0 && C > 0 && count > 0, "bn_finalize: bad sizes");
+  FRX_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats come together");
+  FRX_ENTER(device);
+  hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, partial, rows, C,
+                     (double)count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
+  FRX_LAUNCH_CHECK();
+  return FRX_OK;
+}
+
+extern "C" int frx_bn_eval_affine(int device, frx_stream_t stream, int C, const float* gamma, const float* beta,
+                                  const float* running_mean, const float* running_var, float eps, float* scale,
+                                  float* shift) {
+  FRX_CHECK_ARG(gamma && beta && running_mean && running_var && scale && shift && C > 0, "bn_eval_affine: bad args");
+  FRX_ENTER(device);
+  hipLaunchKernelGGL(k_bn_eval_affine, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, C, gamma, beta,
+                     running_mean, running_var, eps, scale, shift);
+  FRX_LAUNCH_CHECK();
+  return FRX_OK;
+}
+
+extern "C" int frx_block_merge_fwd(int device, frx_stream_t stream, int dtype, int64_t rows, int C, const void* y3,
+                                   const float* s3, const float* b3, const void* idn, const float* sd,
+                                   const float* bd, void* out) {
+  FRX_DT_CHECK(dtype);
+  FRX_CHECK_ARG(y3 && s3 && b3 && idn && out && rows > 0 && C % FRX_VEC(dtype) == 0, "block_merge_fwd: bad args");
+  FRX_CHECK_ARG((sd == nullptr) == (bd == nullptr), "block_merge_fwd: sd/bd come together");
+  FRX_ENTER(device);
+  const long nvec = rows * C / FRX_VEC(dtype);
+  if (dtype == FRX_BF16)
+    hipLaunchKernelGGL(k_merge_fwd<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, nvec, C,
+                       (const bf16_t*)y3, s3, b3, (const bf16_t*)idn, sd, bd, (bf16_t*)out);
+  else
+    hipLaunchKernelGGL(k_merge_fwd<float>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, nvec, C,
+                       (const float*)y3, s3, b3, (const float*)idn, sd, bd, (float*)out);
+  FRX_LAUNCH_CHECK();
+  return FRX_OK;
+}
+
+extern "C" int frx_bn_bwd_partial_rows(int64_t rows, int C) {
+  long b = (rows + 31) / 32;
+  if (b > 1024) b = 1024;
+  if (b < 1) b = 1;
+  (void)C;
+  return (int)b;
+}
+
+extern "C" int frx_bn_bwd_reduce(int device, frx_stream_t stream, int dtype, int64_t rows, int C, const void* g,
+                                 const void* y, const void* out, const float* scale, const float* shift, int relu,
+                                 const float* mean, const float* invstd, void* dz_out, float* partial) {
+  FRX_DT_CHECK(dtype);
+  FRX_CHECK_ARG(g && y && mean && invstd && partial && rows > 0, "bn_bwd_reduce: bad args");
+  const int V = FRX_VEC(dtype), groups = C / V;
+  FRX_CHECK_ARG(C % V == 0 && (groups >= 256 ? groups % 256 == 0 : 256 % groups == 0),
+                "bn_bwd_reduce: C=%d must give a power-of-two number of 16-byte groups", C);
+  FRX_CHECK_ARG(out || !relu || (scale && shift), "bn_bwd_reduce: ReLU mask needs out or scale/shift");
+  FRX_ENTER(device);
+  const int nblk = frx_bn_bwd_partial_rows(rows, C);
+  if (dtype == FRX_BF16)
+    hipLaunchKernelGGL(k_bn_bwd_reduce<bf16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (long)rows, C,
+                       (const bf16_t*)g, (const bf16_t*)y, (const bf16_t*)out, scale, shift, relu, mean, invstd,
+                       (bf16_t*)dz_out, partial);
+  else
+    hipLaunchKernelGGL(k_bn_bwd_reduce<float>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (long)rows, C,
+                       (const float*)g, (const float*)y, (const float*)out, scale, shift, relu, mean, invstd,
+                       (float*)dz_out, partial);
+  FRX_LAUNCH_CHECK();
+  return FRX_OK;
+}
+
+extern "C" int frx_bn_bwd_finalize(int device, frx_stream_t stream, const float* partial, int nblk, int C,
+                                   int64_t count, const float* gamma, const float* invstd, float* dgamma,
+                                   float* dbeta, float* coef) {
+  FRX_CHECK_ARG(partial && gamma && invstd && coef && nblk > 0 && C > 0 && count > 0, "bn_bwd_finalize: bad args");
+  FRX_ENTER(device);
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, partial, nblk, C,
+                     (double)count, gamma, invstd, dgamma, dbeta, coef);
+  FRX_LAUNCH_CHECK();
+  return FRX_OK;
+}
+
+extern "C" int frx_bn_bwd_apply(int device, frx_stream_t stream, int dtype, int64_t rows, int C, const void* g,
+                                const void* y, const void* out, const float* scale, const float* shift, int relu,
+                                const float* mean, const float* invstd, const float* coef, void* dy) {
+  FRX_DT_CHECK(dtype);
+  FRX_CHECK_ARG(g && y && mean && invstd && coef && dy && rows > 0 && C % FRX_VEC(dtype) == 0, "bn_bwd_apply: bad args");
+  FRX_CHECK_ARG(out || !relu || (scale && shift), "bn_bwd_apply: ReLU mask needs out or scale/shift");
+  FRX_ENTER(device);
+  const long nvec = rows * C / FRX_VEC(dtype);
+  if (dtype == FRX_BF16)
+    hipLaunchKernelGGL(k_bn_bwd_apply<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, nvec, C,
+                       (const bf16_t*)g, (const bf16_t*)y, (const bf16_t*)out, scale, shift, relu, mean, invstd, coef,
+                       (bf16_t*)dy);
+  else
+    hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, nvec, C,
+                       (const float*)g, (const float*)y, (const float*)out, scale, shift, relu, mean, invstd, coef,
+                       (float*)dy);
+  FRX_LAUNCH_CHECK();
+  return FRX_OK;
+}
+
+extern "C" int frx_stem_pool_fwd(int device, frx_stream_t stream, int dtype, int N, int H, int W, int C,
+                                 const void* y, const float* scale, const float* shift, void* out, uint8_t* argmax) {
+  FRX_DT_CHECK(dtype);
+  FRX_CHECK_ARG(y && scale && shift && out && argmax && N > 0 && H > 1 && W > 1 && C > 0, "stem_pool_fwd: bad args");
+  FRX_ENTER(device);
+  const long total = (long)N * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * C;
+  if (dtype == FRX_BF16)
+    hipLaunchKernelGGL(k_pool_fwd<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, N, H, W, C,
+                       (const bf16_t*)y, scale, shift, (bf16_t*)out, argmax);
+  else
+    hipLaunchKernelGGL(k_pool_fwd<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, N, H, W, C,
+                       (const float*)y, scale, shift, (float*)out, argmax);
+  FRX_LAUNCH_CHECK();
+  return FRX_OK;
+}
+
+extern "C" int frx_stem_pool_bwd(int device, frx_stream_t stream, int dtype, int N, int H, int W, int C,
+                                 const void* dout, const uint8_t* argmax, void* dpost) {
+  FRX_DT_CHECK(dtype);
+  FRX_CHECK_ARG(dout && argmax && dpost && N > 0 && H > 1 && W > 1 && C > 0, "stem_pool_bwd: bad args");
+  FRX_ENTER(device);
+  const long total = (long)N * H * W * C;
+  if (dtype == FRX_BF16)
+    hipLaunchKernelGGL(k_pool_bwd<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, N, H, W, C,
+                       (const bf16_t*)dout, argmax, (bf16_t*)dpost);
+  else
+    hipLaunchKernelGGL(k_pool_bwd<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, N, H, W, C,
+                       (const float*)dout, argmax, (float*)dpost);
+  FRX_LAUNCH_CHECK();
+  return FRX_OK;
+}
+
+extern "C" int frx_avgpool_fwd(int device, frx_stream_t stream, int dtype, int N, int HW, int C, const void* x, void* out) {
+  FRX_DT_CHECK(dtype);
+  FRX_CHECK_ARG(x && out && N > 0 && HW > 0 && C > 0, "avgpool_fwd: bad args");
+  FRX_ENTER(device);
+  if (dtype == FRX_BF16)
+    hipLaunchKernelGGL(k_avgpool_fwd<bf16_t>, dim3(ew_grid((long)N * C)), dim3(256), 0, (hipStream_t)stream, N, HW, C,
+                       (const bf16_t*)x, (bf16_t*)out);
+  else
+    hipLaunchKernelGGL(k_avgpool_fwd<float>, dim3(ew_grid((long)N * C)), dim3(256), 0, (hipStream_t)stream, N, HW, C,
+                       (const float*)x, (float*)out);
+  FRX_LAUNCH_CHECK();
+  return FRX_OK;
+}
+
+extern "C" int frx_avgpool_bwd(int device, frx_stream_t stream, int dtype, int N, int HW, int C, const void* dpool, void* dx) {
+  FRX_DT_CHECK(dtype);
+  FRX_CHECK_ARG(dpool && dx && N > 0 && HW > 0 && C > 0, "avgpool_bwd: bad args");
+  FRX_ENTER(device);
+  if (dtype == FRX_BF16)
+    hipLaunchKernelGGL(k_avgpool_bwd<bf16_t>, dim3(ew_grid((long)N * HW * C)), dim3(256), 0, (hipStream_t)stream, N, HW, C,
+                       (const bf16_t*)dpool, (bf16_t*)dx);
+  else
+    hipLaunchKernelGGL(k_avgpool_bwd<float>, dim3(ew_grid((long)N * HW * C)), dim3(256), 0, (hipStream_t)stream, N, HW, C,
+                       (const float*)dpool, (float*)dx);
+  FRX_LAUNCH_CHECK();
+  return FRX_OK;
+}

@@ -1,0 +1,156 @@
+// C-ABI entry points for the implicit-GEMM convolutions (kernels in conv_kernels.h).
+// Reference call sites replaced: every nn.Conv2d / nn.Linear of the torchvision ResNet-50 the
+// reference builds in main_code/utils/backbones.py:16-18, forward and autograd backward
+// (main_code/utils/criterion.py:320, model_utils.py:177,185).
+#include "conv_kernels.h"
+
+namespace frx {
+
+struct TileCfg { int bm, bn; };
+
+static TileCfg pick_tile(long M, int Ncol) {
+  if (Ncol <= 64) return {128, 64};
+  const long tiles128 = ((M + 127) / 128) * ((Ncol + 127) / 128);
+  if (tiles128 < 384) return {64, 64};     // small problems: fill the 256 CUs
+  return {128, 128};
+}
+
+template <typename T>
+static int launch_igemm(hipStream_t st, ConvArgs a) {
+  const TileCfg c = pick_tile(a.M, a.Ncol);
+  a.tilesM = cdiv(a.M, c.bm);
+  a.tilesN = cdiv(a.Ncol, c.bn);
+  const int grid = (int)round_up(a.tilesM, 8) * a.tilesN;
+  if (c.bm == 128 && c.bn == 128) hipLaunchKernelGGL((k_igemm<T, 128, 128, 2, 2>), dim3(grid), dim3(256), 0, st, a);
+  else if (c.bm == 128 && c.bn == 64) hipLaunchKernelGGL((k_igemm<T, 128, 64, 2, 2>), dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((k_igemm<T, 64, 64, 2, 2>), dim3(grid), dim3(256), 0, st, a);
+  FRX_LAUNCH_CHECK();
+  return FRX_OK;
+}
+
+static int check_conv(const frx_conv_desc* d) {
+  FRX_CHECK_ARG(d != nullptr, "conv desc is NULL");
+  FRX_CHECK_ARG(d->dtype == FRX_F32 || d->dtype == FRX_BF16, "conv dtype %d unsupported", d->dtype);
+  FRX_CHECK_ARG(d->N > 0 && d->Hi > 0 && d->Wi > 0 && d->Ci > 0 && d->Co > 0, "conv dims must be positive");
+  FRX_CHECK_ARG(d->stride == 1 || d->stride == 2, "conv stride %d unsupported (1 or 2)", d->stride);
+  const int ce = d->dtype == FRX_BF16 ? 32 : 16;
+  if (d->stem) {
+    FRX_CHECK_ARG(d->R == 7 && d->S == 7 && d->stride == 2 && d->pad == 3 && d->Ci == 3,
+                  "stem conv must be 7x7 stride 2 pad 3 on 3 channels");
+    FRX_CHECK_ARG(d->Ho == (d->Hi + 6 - 7) / 2 + 1 && d->Wo == (d->Wi + 6 - 7) / 2 + 1, "stem output size mismatch");
+  } else {
+    FRX_CHECK_ARG(d->Ci % ce == 0, "conv Ci=%d must be a multiple of %d for this dtype", d->Ci, ce);
+    FRX_CHECK_ARG(d->Co % ce == 0, "conv Co=%d must be a multiple of %d for this dtype (dgrad contraction)", d->Co, ce);
+    FRX_CHECK_ARG(d->Ho == (d->Hi + 2 * d->pad - d->R) / d->stride + 1 && d->Wo == (d->Wi + 2 * d->pad - d->S) / d->stride + 1,
+                  "conv output size mismatch: got %dx%d", d->Ho, d->Wo);
+  }
+  FRX_CHECK_ARG((long)d->N * d->Hi * d->Wi < (1L << 31) / 4, "conv too large for 32-bit pixel indices");
+  return FRX_OK;
+}
+
+}  // namespace frx
+using namespace frx;
+
+extern "C" int frx_conv_stat_rows(const frx_conv_desc* d) {
+  if (check_conv(d) != FRX_OK) return -1;
+  const long M = (long)d->N * d->Ho * d->Wo;
+  return cdiv(M, pick_tile(M, d->Co).bm);
+}
+
+extern "C" int frx_stem_padded_dims(int Hi, int Wi, int* Hp, int* Wp) {
+  FRX_CHECK_ARG(Hp && Wp && Hi > 0 && Wi > 0, "stem_padded_dims: bad args");
+  // 3 pixels of zero border on each side; the 8-tap (32-element) row read of the last output
+  // pixel ends at column 2*(Wo-1)+7, so round the width up to an even count that covers it.
+  const int Wo = (Wi + 6 - 7) / 2 + 1, Ho = (Hi + 6 - 7) / 2 + 1;
+  *Hp = 2 * (Ho - 1) + 7 > Hi + 6 ? 2 * (Ho - 1) + 7 : Hi + 6;
+  int w = 2 * (Wo - 1) + 8;
+  if (w < Wi + 6) w = Wi + 6;
+  *Wp = (w + 1) & ~1;
+  return FRX_OK;
+}
+
+extern "C" int frx_conv_fwd(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x,
+                            const void* w, const float* in_scale, const float* in_shift, int in_relu,
+                            const float* bias, void* y, int out_f32, float* stat_partial) {
+  if (int rc = check_conv(d)) return rc;
+  FRX_CHECK_ARG(x && w && y, "conv_fwd: NULL pointer");
+  FRX_CHECK_ARG(!(d->stem && in_scale), "conv_fwd: the stem takes the raw image (no prologue)");
+  FRX_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "conv_fwd: in_scale/in_shift must come together");
+  FRX_ENTER(device);
+  ConvArgs a{};
+  a.X = x; a.W = w; a.Y = y;
+  a.in_scale = in_scale; a.in_shift = in_shift; a.in_relu = in_relu;
+  a.bias = bias; a.stat_partial = stat_partial; a.out_f32 = out_f32;
+  a.N = d->N; a.Ho = d->Ho; a.Wo = d->Wo; a.Ncol = d->Co; a.R = d->R; a.S = d->S;
+  a.stride = d->stride; a.pad = d->pad;
+  a.M = d->N * d->Ho * d->Wo;
+  if (d->stem) {
+    int hp, wp;
+    frx_stem_padded_dims(d->Hi, d->Wi, &hp, &wp);
+    a.mode = MODE_STEM; a.Hx = hp; a.Wx = wp; a.Kc = 4;
+  } else {
+    a.mode = MODE_FWD; a.Hx = d->Hi; a.Wx = d->Wi; a.Kc = d->Ci;
+  }
+  return d->dtype == FRX_BF16 ? launch_igemm<bf16_t>((hipStream_t)stream, a) : launch_igemm<float>((hipStream_t)stream, a);
+}
+
+extern "C" int frx_conv_dgrad(int device, frx_stream_t stream, const frx_conv_desc* d, const void* dy,
+                              const void* w_crsk, const void* addend, void* dx) {
+  if (int rc = check_conv(d)) return rc;
+  FRX_CHECK_ARG(!d->stem, "conv_dgrad: the stem has no input gradient");
+  FRX_CHECK_ARG(dy && w_crsk && dx, "conv_dgrad: NULL pointer");
+  FRX_ENTER(device);
+  ConvArgs a{};
+  a.X = dy; a.W = w_crsk; a.Y = dx; a.addend = addend;
+  a.N = d->N; a.Hx = d->Ho; a.Wx = d->Wo; a.Kc = d->Co;
+  a.Ho = d->Hi; a.Wo = d->Wi; a.Ncol = d->Ci; a.R = d->R; a.S = d->S;
+  a.stride = d->stride; a.pad = d->pad;
+  a.M = d->N * d->Hi * d->Wi;
+  a.mode = MODE_DGRAD;
+  return d->dtype == FRX_BF16 ? launch_igemm<bf16_t>((hipStream_t)stream, a) : launch_igemm<float>((hipStream_t)stream, a);
+}
+
+extern "C" int frx_conv_wgrad(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x,
+                              const float* in_scale, const float* in_shift, int in_relu, const void* dy,
+                              float* dw) {
+  if (int rc = check_conv(d)) return rc;
+  FRX_CHECK_ARG(x && dy && dw, "conv_wgrad: NULL pointer");
+  FRX_CHECK_ARG(!(d->stem && in_scale), "conv_wgrad: the stem takes the raw image (no prologue)");
+  FRX_ENTER(device);
+  WgradArgs a{};
+  a.X = x; a.dY = dy; a.dW = dw;
+  a.in_scale = in_scale; a.in_shift = in_shift; a.in_relu = in_relu;
+  a.N = d->N; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co; a.R = d->R; a.S = d->S;
+  a.stride = d->stride; a.pad = d->pad; a.M = d->N * d->Ho * d->Wo; a.stem = d->stem;
+  int taps = d->R * d->S;
+  int ci_extent = d->Ci;
+  if (d->stem) {
+    int hp, wp;
+    frx_stem_padded_dims(d->Hi, d->Wi, &hp, &wp);
+    a.Hx = hp; a.Wx = wp; a.S = 1; taps = d->R; ci_extent = 32;
+  } else {
+    a.Hx = d->Hi; a.Wx = d->Wi;
+  }
+  const int kp = d->dtype == FRX_BF16 ? 32 : 16;
+  const int bt = (d->Co <= 64 || ci_extent <= 64) ? 64 : 128;
+  a.tilesCo = cdiv(d->Co, bt);
+  a.tilesCi = cdiv(ci_extent, bt);
+  const int nchunks = cdiv(a.M, kp);
+  const int tiles = a.tilesCo * a.tilesCi * taps;
+  int splits = cdiv(1024, tiles);
+  if (splits > cdiv(nchunks, 8)) splits = cdiv(nchunks, 8);
+  if (splits < 1) splits = 1;
+  a.chunks_per_split = cdiv(nchunks, splits);
+  splits = cdiv(nchunks, a.chunks_per_split);
+  dim3 grid(a.tilesCo * a.tilesCi, taps, splits), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (d->dtype == FRX_BF16) {
+    if (bt == 64) hipLaunchKernelGGL((k_wgrad<bf16_t, 64>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_wgrad<bf16_t, 128>), grid, block, 0, st, a);
+  } else {
+    if (bt == 64) hipLaunchKernelGGL((k_wgrad<float, 64>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((k_wgrad<float, 128>), grid, block, 0, st, a);
+  }
+  FRX_LAUNCH_CHECK();
+  return FRX_OK;
+}

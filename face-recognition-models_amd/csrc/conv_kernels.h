@@ -1,0 +1,470 @@
+// Implicit-GEMM convolution kernels for gfx950 (NHWC activations, K-contiguous weights).
+//
+//   forward : Y[m, co]  = sum_{r,s,ci} f(X)[pix(m,r,s), ci] * W[co][r][s][ci]       (KRSC weights)
+//   dgrad   : dX[m, ci] = sum_{r,s,co} dY[pixT(m,r,s), co]  * Wt[ci][r][s][co]      (CRSK weights)
+//   wgrad   : dW[co][r][s][ci] += sum_m dY[m, co] * f(X)[pix(m,r,s), ci]            (split-K, fp32 atomics)
+//
+// f(X) = relu(scale[c]*x + shift[c]) is the previous layer's train-mode BatchNorm + ReLU,
+// applied while the tile is staged into LDS so the normalised activation never exists in
+// HBM.  One K-chunk = 64 bytes of the contraction axis per row (32 bf16 / 16
+// fp32), so the bf16 and fp32 instantiations share the staging code, the LDS image and
+// its swizzle byte for byte; only the MFMA differs:
+//   bf16: v_mfma_f32_16x16x32_bf16 on the lane's 16-byte fragment
+//   fp32: 4 x v_mfma_f32_16x16x4_f32 on the 4 floats of the same 16 bytes (exact fp32 chain;
+//         k order inside a chunk is permuted identically for A and B, which a sum allows)
+#pragma once
+#include "frx_common.h"
+
+namespace frx {
+
+template <typename T> struct TT;
+template <> struct TT<float>  { static constexpr int VEC = 4, CE = 16; };
+template <> struct TT<bf16_t> { static constexpr int VEC = 8, CE = 32; };
+
+enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_STEM = 2 };
+
+struct ConvArgs {
+  const void* X;          // gathered operand: activations (fwd / wgrad) or dY (dgrad)
+  const void* W;          // [Ncol][R][S][Kc] (fwd: KRSC, dgrad: CRSK)
+  void* Y;                // [M][Ncol]
+  const float* in_scale;  // optional [Kc]: prologue affine on X ...
+  const float* in_shift;
+  int in_relu;            // ... followed by ReLU
+  const float* bias;      // optional [Ncol]
+  const void* addend;     // optional [M][Ncol] (same dtype as Y unless out_f32): Y = acc + addend
+  float* stat_partial;    // optional [tilesM][2][Ncol]: column sums / sums of squares of Y
+  int out_f32;            // store Y as fp32 regardless of T
+  int N, Hx, Wx, Kc;      // geometry of X (Kc = its channel count)
+  int Ho, Wo;             // output spatial size; M = N*Ho*Wo
+  int Ncol, R, S, stride, pad;
+  int M;
+  int mode;
+  int tilesM, tilesN;
+};
+
+// ds_read_b128 of a [rows][64 B] image is 2-way bank-conflicted for the 16x16x32 fragment
+// pattern (row = lane&15, chunk = lane>>4); XOR-ing the 16-byte chunk index with h[(row>>2)&3],
+// h = {0,2,3,1}, makes every 16-lane service group hit 16 distinct slots.
+__device__ __forceinline__ int swz64(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }
+
+template <typename T>
+__device__ __forceinline__ uint4 bn_relu_vec(uint4 raw, const float* __restrict__ sc,
+                                             const float* __restrict__ sh, int relu) {
+  if constexpr (sizeof(T) == 4) {
+    const float4 s = *reinterpret_cast<const float4*>(sc);
+    const float4 b = *reinterpret_cast<const float4*>(sh);
+    float4 v = *reinterpret_cast<float4*>(&raw);
+    v.x = fmaf(v.x, s.x, b.x); v.y = fmaf(v.y, s.y, b.y); v.z = fmaf(v.z, s.z, b.z); v.w = fmaf(v.w, s.w, b.w);
+    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    return *reinterpret_cast<uint4*>(&v);
+  } else {
+    bf16x8 v = *reinterpret_cast<bf16x8*>(&raw);
+    const float4 s0 = *reinterpret_cast<const float4*>(sc), s1 = *reinterpret_cast<const float4*>(sc + 4);
+    const float4 b0 = *reinterpret_cast<const float4*>(sh), b1 = *reinterpret_cast<const float4*>(sh + 4);
+    const float ss[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+    const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float f = fmaf((float)v[j], ss[j], bb[j]);
+      if (relu) f = fmaxf(f, 0.f);
+      o[j] = (bf16_t)f;
+    }
+    return *reinterpret_cast<uint4*>(&o);
+  }
+}
+
+template <typename T> __device__ __forceinline__ float load_as_float(const void* p, long i) {
+  if constexpr (sizeof(T) == 4) return reinterpret_cast<const float*>(p)[i];
+  else return (float)reinterpret_cast<const bf16_t*>(p)[i];
+}
+
+// ------------------------------------------------------------------------------------------
+// forward / dgrad / stem: BM x BN output tile, 4 waves as WM x WN, double-buffered LDS,
+// one barrier per K-chunk, global loads of chunk k+1 in flight under the MFMAs of chunk k.
+// ------------------------------------------------------------------------------------------
+template <typename T, int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void k_igemm(ConvArgs a) {
+  constexpr int VEC = TT<T>::VEC, CE = TT<T>::CE;
+  constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 16, FN = WTN / 16;
+  constexpr int ALD = BM / 64, BLD = BN / 64;
+  constexpr int STAGE = (BM + BN) * 64;
+  static_assert(WM * WN == 4 && WTM % 16 == 0 && WTN % 16 == 0, "bad wave tiling");
+  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+
+  // XCD-aware tile order: blocks that share an A row-panel (same mt) share an XCD's L2.
+  const int bid = blockIdx.x;
+  const int xcd = bid & 7, local = bid >> 3;
+  const int mt = (local / a.tilesN) * 8 + xcd, nt = local % a.tilesN;
+  if (mt >= a.tilesM) return;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int chunk = tid & 3, srow = tid >> 2;
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.X);
+  const T* __restrict__ Wp = reinterpret_cast<const T*>(a.W);
+  const int Ktot = a.R * a.S * a.Kc;
+  const int nk = (a.mode == MODE_STEM) ? (a.R * 32) / CE : Ktot / CE;
+  const int ldw = (a.mode == MODE_STEM) ? a.R * 32 : Ktot;   // weight row length in elements
+
+  // ---- per-thread gather bookkeeping (rows fixed across the K loop)
+  int rn[ALD], rh[ALD], rw[ALD];
+  bool rok[ALD];
+#pragma unroll
+  for (int i = 0; i < ALD; ++i) {
+    const int m = m0 + srow + 64 * i;
+    rok[i] = m < a.M;
+    const int mm = rok[i] ? m : 0;
+    const int hw = a.Ho * a.Wo;
+    const int n = mm / hw, rem = mm - n * hw;
+    const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+    rn[i] = n;
+    if (a.mode == MODE_FWD) { rh[i] = oh * a.stride - a.pad; rw[i] = ow * a.stride - a.pad; }
+    else if (a.mode == MODE_DGRAD) { rh[i] = oh + a.pad; rw[i] = ow + a.pad; }
+    else { rh[i] = oh * 2; rw[i] = ow * 2; }
+  }
+  const T* bptr[BLD];
+  bool bok[BLD];
+#pragma unroll
+  for (int i = 0; i < BLD; ++i) {
+    const int n = n0 + srow + 64 * i;
+    bok[i] = n < a.Ncol;
+    bptr[i] = Wp + (long)(bok[i] ? n : 0) * ldw + chunk * VEC;
+  }
+
+  int tr = 0, ts = 0, c0 = 0;   // current tap (r, s) and channel offset of the K-chunk
+  uint4 ra[ALD], rb[BLD];
+
+  auto load_chunk = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < ALD; ++i) {
+      bool ok = rok[i];
+      long off;
+      if (a.mode == MODE_FWD) {
+        const int hi = rh[i] + tr, wi = rw[i] + ts;
+        ok = ok && (unsigned)hi < (unsigned)a.Hx && (unsigned)wi < (unsigned)a.Wx;
+        off = (((long)rn[i] * a.Hx + hi) * a.Wx + wi) * a.Kc + c0 + chunk * VEC;
+      } else if (a.mode == MODE_DGRAD) {
+        const int th = rh[i] - tr, tw = rw[i] - ts;
+        const int sm = a.stride - 1, sh = a.stride >> 1;   // stride is 1 or 2
+        ok = ok && th >= 0 && tw >= 0 && ((th & sm) == 0) && ((tw & sm) == 0);
+        const int hi = th >> sh, wi = tw >> sh;
+        ok = ok && hi < a.Hx && wi < a.Wx;
+        off = (((long)rn[i] * a.Hx + hi) * a.Wx + wi) * a.Kc + c0 + chunk * VEC;
+      } else {  // stem: physically padded NHWC4 input, row tr, 8 taps x 4 channels = 32 elements
+        off = (((long)rn[i] * a.Hx + rh[i] + tr) * a.Wx + rw[i]) * 4 + c0 + chunk * VEC;
+      }
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (ok) {
+        v = *reinterpret_cast<const uint4*>(X + off);
+        if (a.in_scale) v = bn_relu_vec<T>(v, a.in_scale + c0 + chunk * VEC, a.in_shift + c0 + chunk * VEC, a.in_relu);
+      }
+      ra[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < BLD; ++i)
+      rb[i] = bok[i] ? *reinterpret_cast<const uint4*>(bptr[i] + (long)kc * CE) : make_uint4(0, 0, 0, 0);
+    // advance the tap walker to chunk kc+1
+    c0 += CE;
+    const int span = (a.mode == MODE_STEM) ? 32 : a.Kc;
+    if (c0 >= span) { c0 = 0; if (a.mode == MODE_STEM) { ++tr; } else if (++ts == a.S) { ts = 0; ++tr; } }
+  };
+  auto store_chunk = [&](int buf) {
+    char* As = smem + buf * STAGE;
+    char* Bs = As + BM * 64;
+#pragma unroll
+    for (int i = 0; i < ALD; ++i) {
+      const int row = srow + 64 * i;
+      *reinterpret_cast<uint4*>(As + (row * 4 + (chunk ^ swz64(row))) * 16) = ra[i];
+    }
+#pragma unroll
+    for (int i = 0; i < BLD; ++i) {
+      const int row = srow + 64 * i;
+      *reinterpret_cast<uint4*>(Bs + (row * 4 + (chunk ^ swz64(row))) * 16) = rb[i];
+    }
+  };
+
+  f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  load_chunk(0);
+  store_chunk(0);
+  __syncthreads();
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int kc = 0; kc < nk; ++kc) {
+    const int cur = kc & 1;
+    if (kc + 1 < nk) load_chunk(kc + 1);
+    const char* As = smem + cur * STAGE;
+    const char* Bs = As + BM * 64;
+    uint4 fa[FM], fb[FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int row = wm * WTM + i * 16 + fr;
+      fa[i] = *reinterpret_cast<const uint4*>(As + (row * 4 + (fq ^ swz64(row))) * 16);
+    }
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int row = wn * WTN + j * 16 + fr;
+      fb[j] = *reinterpret_cast<const uint4*>(Bs + (row * 4 + (fq ^ swz64(row))) * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        if constexpr (sizeof(T) == 2) {
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&fa[i]),
+                                                              *reinterpret_cast<bf16x8*>(&fb[j]), acc[i][j], 0, 0, 0);
+        } else {
+          const float* pa = reinterpret_cast<const float*>(&fa[i]);
+          const float* pb = reinterpret_cast<const float*>(&fb[j]);
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[q], pb[q], acc[i][j], 0, 0, 0);
+        }
+      }
+    if (kc + 1 < nk) store_chunk(cur ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue.  C/D map: col = lane&15, row = (lane>>4)*4 + reg
+  float csum[FN], csq[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int n = n0 + wn * WTN + j * 16 + fr;
+      const float bias = (a.bias && n < a.Ncol) ? a.bias[n] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * WTM + i * 16 + fq * 4 + r;
+        if (m < a.M && n < a.Ncol) {
+          float v = acc[i][j][r] + bias;
+          const long o = (long)m * a.Ncol + n;
+          if (a.out_f32) {
+            if (a.addend) v += reinterpret_cast<const float*>(a.addend)[o];
+            reinterpret_cast<float*>(a.Y)[o] = v;
+          } else {
+            if (a.addend) v += load_as_float<T>(a.addend, o);
+            const T t = (T)v;
+            reinterpret_cast<T*>(a.Y)[o] = t;
+            v = (float)t;       // statistics of the values the next layer will read
+          }
+          csum[j] += v;
+          csq[j] += v * v;
+        }
+      }
+    }
+  if (a.stat_partial) {
+    float* red = reinterpret_cast<float*>(smem);   // [2][WM][BN]; K loop ended with a barrier
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      float s = csum[j], q = csq[j];
+      s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
+      q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
+      if (fq == 0) {
+        red[(0 * WM + wm) * BN + wn * WTN + j * 16 + fr] = s;
+        red[(1 * WM + wm) * BN + wn * WTN + j * 16 + fr] = q;
+      }
+    }
+    __syncthreads();
+    for (int t = tid; t < 2 * BN; t += 256) {
+      const int which = t / BN, col = t % BN;
+      if (n0 + col < a.Ncol) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) s += red[(which * WM + w) * BN + col];
+        a.stat_partial[((long)mt * 2 + which) * a.Ncol + n0 + col] = s;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// wgrad.  Contraction runs over pixels, for which BOTH operands are strided in memory
+// (channels are contiguous), so tiles are staged pixel-major [32 px][channels] and the MFMA
+// fragments come out of LDS through the transposing read ds_read_b64_tr_b16 (bf16) or plain
+// 4-byte reads (fp32 MFMA takes one float per lane).  grid = (co tiles * ci tiles, taps, splits).
+// ------------------------------------------------------------------------------------------
+struct WgradArgs {
+  const void* X;          // activations [N,Hx,Wx,Ci] (or padded NHWC4 for the stem)
+  const void* dY;         // [M][Co]
+  float* dW;              // fp32 [Co][R][S][Ci] (stem: [Co][R][8][4]); accumulated with atomics
+  const float* in_scale;  // prologue on X, as in forward
+  const float* in_shift;
+  int in_relu;
+  int N, Hx, Wx, Ci, Ho, Wo, Co, R, S, stride, pad, M;
+  int stem;
+  int tilesCo, tilesCi;
+  int chunks_per_split;   // K-chunks (of KP pixels) per blockIdx.z
+};
+
+// XOR swizzle of the 32-byte slot inside a pixel row so the 8 pixel rows a half-wave touches
+// in one transposing read fall on distinct banks (row bytes RB = 2*BT for bf16).
+template <int RB> __device__ __forceinline__ int tr_swz(int row) {
+  if constexpr (RB >= 256) return (((row & 3) | (((row >> 3) & 1) << 2)) << 5);
+  else return ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 5);
+}
+
+template <typename T, int BT>   // BT x BT output tile (co x ci)
+__global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
+  constexpr int VEC = TT<T>::VEC;
+  constexpr int KP = (sizeof(T) == 2) ? 32 : 16;   // pixels per K-chunk
+  constexpr int RB = BT * sizeof(T);               // bytes per pixel row of a tile
+  constexpr int CPR = RB / 16;                     // 16-byte chunks per row
+  constexpr int LD = (KP * CPR) / 256;             // 16-byte loads per thread per operand
+  constexpr int WT = BT / 2, F = WT / 16;          // 2x2 waves
+  static_assert(LD >= 1, "tile too small");
+  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KP * RB];
+
+  const int tile = blockIdx.x;
+  const int cot = tile / a.tilesCi, cit = tile % a.tilesCi;
+  const int tap = blockIdx.y;
+  const int tr_ = tap / a.S, ts_ = tap % a.S;
+  const int co0 = cot * BT, ci0 = cit * BT;
+  const int nchunks = (a.M + KP - 1) / KP;
+  const int kbeg = blockIdx.z * a.chunks_per_split;
+  const int kend = min(nchunks, kbeg + a.chunks_per_split);
+  if (kbeg >= kend) return;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const T* __restrict__ X = reinterpret_cast<const T*>(a.X);
+  const T* __restrict__ dY = reinterpret_cast<const T*>(a.dY);
+  const int hw = a.Ho * a.Wo;
+  const int xch = a.stem ? 32 : a.Ci;   // channels (elements) addressable in the X row for this tap-row
+
+  uint4 ry[LD], rx[LD];
+  auto load_chunk = [&](int kc) {
+#pragma unroll
+    for (int i = 0; i < LD; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx / CPR, ch = idx % CPR;
+      const int m = kc * KP + row;
+      const bool mok = m < a.M;
+      // dY tile
+      const int co = co0 + ch * VEC;
+      ry[i] = (mok && co < a.Co) ? *reinterpret_cast<const uint4*>(dY + (long)m * a.Co + co) : make_uint4(0, 0, 0, 0);
+      // X tile (gathered at this tap)
+      const int ci = ci0 + ch * VEC;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (mok && ci < xch) {
+        const int n = m / hw, rem = m - n * hw;
+        const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+        if (a.stem) {
+          const long off = (((long)n * a.Hx + oh * 2 + tr_) * a.Wx + ow * 2) * 4 + ci;
+          v = *reinterpret_cast<const uint4*>(X + off);
+        } else {
+          const int hi = oh * a.stride - a.pad + tr_, wi = ow * a.stride - a.pad + ts_;
+          if ((unsigned)hi < (unsigned)a.Hx && (unsigned)wi < (unsigned)a.Wx) {
+            v = *reinterpret_cast<const uint4*>(X + (((long)n * a.Hx + hi) * a.Wx + wi) * a.Ci + ci);
+            if (a.in_scale) v = bn_relu_vec<T>(v, a.in_scale + ci, a.in_shift + ci, a.in_relu);
+          }
+        }
+      }
+      rx[i] = v;
+    }
+  };
+  auto store_chunk = [&](int buf) {
+    char* Ys = smem + buf * (2 * KP * RB);
+    char* Xs = Ys + KP * RB;
+#pragma unroll
+    for (int i = 0; i < LD; ++i) {
+      const int idx = tid + 256 * i;
+      const int row = idx / CPR, ch = idx % CPR;
+      const int off = row * RB + ((ch * 16) ^ (sizeof(T) == 2 ? tr_swz<RB>(row) : 0));
+      *reinterpret_cast<uint4*>(Ys + off) = ry[i];
+      *reinterpret_cast<uint4*>(Xs + off) = rx[i];
+    }
+  };
+
+  f32x4 acc[F][F];
+#pragma unroll
+  for (int i = 0; i < F; ++i)
+#pragma unroll
+    for (int j = 0; j < F; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  load_chunk(kbeg);
+  store_chunk(0);
+  __syncthreads();
+  const int fr = lane & 15, fq = lane >> 4;
+  for (int kc = kbeg; kc < kend; ++kc) {
+    const int cur = (kc - kbeg) & 1;
+    if (kc + 1 < kend) load_chunk(kc + 1);
+    const char* Ys = smem + cur * (2 * KP * RB);
+    const char* Xs = Ys + KP * RB;
+    if constexpr (sizeof(T) == 2) {
+      // lane (16g + 4q + p) supplies &tile[pix0 + q][col0 + 4p]; it receives column (lane&15),
+      // rows pix0..pix0+3.  Two reads (pix0 = 8g, 8g+4) build the k = 8g..8g+7 fragment.
+      const int q = (lane >> 2) & 3, p = lane & 3;
+      s16x4 ya[F][2], xb[F][2];
+#pragma unroll
+      for (int i = 0; i < F; ++i)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int row = 8 * fq + 4 * h + q;
+          const int colb = (wr * WT + i * 16 + 4 * p) * 2;
+          ya[i][h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(Ys + row * RB + (colb ^ tr_swz<RB>(row))));
+          const int colx = (wc * WT + i * 16 + 4 * p) * 2;
+          xb[i][h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+              (__attribute__((address_space(3))) s16x4*)(Xs + row * RB + (colx ^ tr_swz<RB>(row))));
+        }
+#pragma unroll
+      for (int i = 0; i < F; ++i)
+#pragma unroll
+        for (int j = 0; j < F; ++j) {
+          typedef short s16x8 __attribute__((ext_vector_type(8)));
+          s16x8 av = __builtin_shufflevector(ya[i][0], ya[i][1], 0, 1, 2, 3, 4, 5, 6, 7);
+          s16x8 bv = __builtin_shufflevector(xb[j][0], xb[j][1], 0, 1, 2, 3, 4, 5, 6, 7);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&av),
+                                                              *reinterpret_cast<bf16x8*>(&bv), acc[i][j], 0, 0, 0);
+        }
+    } else {
+      const float* Yf = reinterpret_cast<const float*>(Ys);
+      const float* Xf = reinterpret_cast<const float*>(Xs);
+#pragma unroll
+      for (int ks = 0; ks < KP / 4; ++ks) {
+        float ya[F], xb[F];
+        const int row = ks * 4 + fq;
+#pragma unroll
+        for (int i = 0; i < F; ++i) {
+          ya[i] = Yf[row * BT + wr * WT + i * 16 + fr];
+          xb[i] = Xf[row * BT + wc * WT + i * 16 + fr];
+        }
+#pragma unroll
+        for (int i = 0; i < F; ++i)
+#pragma unroll
+          for (int j = 0; j < F; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[i], xb[j], acc[i][j], 0, 0, 0);
+      }
+    }
+    if (kc + 1 < kend) store_chunk(cur ^ 1);
+    __syncthreads();
+  }
+
+  const int ldw = a.stem ? 32 : a.Ci;           // elements per (co, r, s-row) line of dW
+  const bool atomic = gridDim.z > 1;
+#pragma unroll
+  for (int i = 0; i < F; ++i)
+#pragma unroll
+    for (int j = 0; j < F; ++j) {
+      const int ci = ci0 + wc * WT + j * 16 + fr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int co = co0 + wr * WT + i * 16 + fq * 4 + r;
+        if (co < a.Co && ci < ldw) {
+          const long o = a.stem ? (((long)co * a.R + tr_) * 32 + ci)
+                                : ((((long)co * a.R + tr_) * a.S + ts_) * a.Ci + ci);
+          if (atomic) atomicAdd(a.dW + o, acc[i][j][r]); else a.dW[o] += acc[i][j][r];
+        }
+      }
+    }
+}
+
+}  // namespace frx

@@ -1,0 +1,195 @@
+// Optimiser, weight-layout preparation, input staging, casts.  HBM-bound helpers.
+// Reference call sites: optim.SGD(momentum 0.9, wd 5e-4) model_utils.py:557,186;
+// ToTensor + Normalize(0.5, 0.5) model_utils.py:539-547; .to(device) :173.
+#include "conv_kernels.h"
+
+namespace frx {
+
+// torch.optim.SGD: d = g*gscale + wd*p;  buf = mu*buf + d;  p -= lr*buf   (buf starts at 0, so the
+// first step's "buf = d" special case is the same arithmetic).  One launch for ALL parameters.
+__global__ __launch_bounds__(256) void k_sgd(long n, float* __restrict__ p, const float* __restrict__ g,
+                                             float* __restrict__ buf, const float* __restrict__ lr_ptr, float lr,
+                                             float mu, float wd, float gscale) {
+  const float rate = lr_ptr ? *lr_ptr : lr;
+  const long nv = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nv; i += (long)gridDim.x * 256) {
+    float4 pp = reinterpret_cast<float4*>(p)[i];
+    const float4 gg = reinterpret_cast<const float4*>(g)[i];
+    float4 bb = reinterpret_cast<float4*>(buf)[i];
+    bb.x = mu * bb.x + (gg.x * gscale + wd * pp.x); pp.x -= rate * bb.x;
+    bb.y = mu * bb.y + (gg.y * gscale + wd * pp.y); pp.y -= rate * bb.y;
+    bb.z = mu * bb.z + (gg.z * gscale + wd * pp.z); pp.z -= rate * bb.z;
+    bb.w = mu * bb.w + (gg.w * gscale + wd * pp.w); pp.w -= rate * bb.w;
+    reinterpret_cast<float4*>(p)[i] = pp;
+    reinterpret_cast<float4*>(buf)[i] = bb;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
+    const long i = (nv << 2) + threadIdx.x;
+    const float b = mu * buf[i] + (g[i] * gscale + wd * p[i]);
+    buf[i] = b;
+    p[i] -= rate * b;
+  }
+}
+
+// master fp32 KRSC -> kernel copies: KRSC in T (forward / wgrad layout) and CRSK in T (dgrad)
+template <typename T>
+__global__ __launch_bounds__(256) void k_weight_prep(int Co, int RS, int Ci, const float* __restrict__ w,
+                                                     T* __restrict__ krsc, T* __restrict__ crsk) {
+  const long total = (long)Co * RS * Ci;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const float v = w[i];
+    if (krsc) krsc[i] = (T)v;
+    if (crsk) {
+      const int ci = (int)(i % Ci);
+      const long t = i / Ci;
+      const int rs = (int)(t % RS);
+      const int co = (int)(t / RS);
+      crsk[((long)ci * RS + rs) * Co + co] = (T)v;
+    }
+  }
+}
+
+// fp32 NCHW image batch (already normalised to [-1,1]) -> zero-bordered NHWC4 in T for the stem
+template <typename T>
+__global__ __launch_bounds__(256) void k_input_prep_f32(int N, int H, int W, int Hp, int Wp,
+                                                        const float* __restrict__ x, T* __restrict__ out) {
+  const long total = (long)N * Hp * Wp;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int wp = (int)(i % Wp);
+    long t = i / Wp;
+    const int hp = (int)(t % Hp);
+    const int n = (int)(t / Hp);
+    const int h = hp - 3, w = wp - 3;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[c] = x[(((long)n * 3 + c) * H + h) * W + w];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) out[i * 4 + c] = (T)v[c];
+  }
+}
+
+// uint8 NHWC (decoder output) -> same layout, fused ToTensor + Normalize(0.5,0.5): x/127.5 - 1
+template <typename T>
+__global__ __launch_bounds__(256) void k_input_prep_u8(int N, int H, int W, int Hp, int Wp,
+                                                       const uint8_t* __restrict__ x, T* __restrict__ out) {
+  const long total = (long)N * Hp * Wp;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int wp = (int)(i % Wp);
+    long t = i / Wp;
+    const int hp = (int)(t % Hp);
+    const int n = (int)(t / Hp);
+    const int h = hp - 3, w = wp - 3;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+      const uint8_t* px = x + (((long)n * H + h) * W + w) * 3;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) v[c] = ((float)px[c] / 255.f - 0.5f) / 0.5f;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) out[i * 4 + c] = (T)v[c];
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_cast_from_f32(long n, const float* __restrict__ x, T* __restrict__ y) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = (T)x[i];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void k_cast_to_f32(long n, const T* __restrict__ x, float* __restrict__ y) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = (float)x[i];
+}
+
+// out[c] += sum_r x[r][c]   (fc bias gradient)
+__global__ __launch_bounds__(256) void k_colsum_f32(int rows, int C, const float* __restrict__ x, float* __restrict__ out) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  float s = 0.f;
+  for (int r = 0; r < rows; ++r) s += x[(long)r * C + c];
+  out[c] += s;
+}
+
+static inline int ew_grid2(long n) {
+  long b = (n + 255) / 256;
+  if (b > 4096) b = 4096;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace frx
+using namespace frx;
+
+extern "C" int frx_sgd_step(int device, frx_stream_t stream, int64_t n, float* p, const float* g, float* buf,
+                            const float* lr_dev, float lr, float momentum, float weight_decay, float grad_scale) {
+  FRX_CHECK_ARG(n >= 0, "sgd_step: n<0");
+  if (n == 0) return FRX_OK;
+  FRX_CHECK_ARG(p && g && buf, "sgd_step: NULL pointer");
+  FRX_CHECK_ARG((((size_t)p | (size_t)g | (size_t)buf) & 15) == 0, "sgd_step: buffers must be 16-byte aligned");
+  FRX_ENTER(device);
+  hipLaunchKernelGGL(k_sgd, dim3(ew_grid2(n / 4 + 1)), dim3(256), 0, (hipStream_t)stream, (long)n, p, g, buf, lr_dev,
+                     lr, momentum, weight_decay, grad_scale);
+  FRX_LAUNCH_CHECK();
+  return FRX_OK;
+}
+
+extern "C" int frx_weight_prep(int device, frx_stream_t stream, int dtype, int Co, int RS, int Ci, const float* master,
+                               void* krsc, void* crsk) {
+  FRX_CHECK_ARG(dtype == FRX_F32 || dtype == FRX_BF16, "weight_prep: dtype");
+  FRX_CHECK_ARG(master && (krsc || crsk) && Co > 0 && RS > 0 && Ci > 0, "weight_prep: bad args");
+  FRX_ENTER(device);
+  const long total = (long)Co * RS * Ci;
+  if (dtype == FRX_BF16)
+    hipLaunchKernelGGL(k_weight_prep<bf16_t>, dim3(ew_grid2(total)), dim3(256), 0, (hipStream_t)stream, Co, RS, Ci,
+                       master, (bf16_t*)krsc, (bf16_t*)crsk);
+  else
+    hipLaunchKernelGGL(k_weight_prep<float>, dim3(ew_grid2(total)), dim3(256), 0, (hipStream_t)stream, Co, RS, Ci,
+                       master, (float*)krsc, (float*)crsk);
+  FRX_LAUNCH_CHECK();
+  return FRX_OK;
+}
+
+extern "C" int frx_input_prep(int device, frx_stream_t stream, int dtype, int N, int H, int W, const void* images,
+                              int is_u8_nhwc, void* out) {
+  FRX_CHECK_ARG(dtype == FRX_F32 || dtype == FRX_BF16, "input_prep: dtype");
+  FRX_CHECK_ARG(images && out && N > 0 && H > 0 && W > 0, "input_prep: bad args");
+  FRX_ENTER(device);
+  int hp, wp;
+  frx_stem_padded_dims(H, W, &hp, &wp);
+  const long total = (long)N * hp * wp;
+  hipStream_t st = (hipStream_t)stream;
+  if (is_u8_nhwc) {
+    if (dtype == FRX_BF16) hipLaunchKernelGGL(k_input_prep_u8<bf16_t>, dim3(ew_grid2(total)), dim3(256), 0, st, N, H, W, hp, wp, (const uint8_t*)images, (bf16_t*)out);
+    else hipLaunchKernelGGL(k_input_prep_u8<float>, dim3(ew_grid2(total)), dim3(256), 0, st, N, H, W, hp, wp, (const uint8_t*)images, (float*)out);
+  } else {
+    if (dtype == FRX_BF16) hipLaunchKernelGGL(k_input_prep_f32<bf16_t>, dim3(ew_grid2(total)), dim3(256), 0, st, N, H, W, hp, wp, (const float*)images, (bf16_t*)out);
+    else hipLaunchKernelGGL(k_input_prep_f32<float>, dim3(ew_grid2(total)), dim3(256), 0, st, N, H, W, hp, wp, (const float*)images, (float*)out);
+  }
+  FRX_LAUNCH_CHECK();
+  return FRX_OK;
+}
+
+extern "C" int frx_cast(int device, frx_stream_t stream, int dtype, int to_f32, int64_t n, const void* x, void* y) {
+  FRX_CHECK_ARG(dtype == FRX_F32 || dtype == FRX_BF16, "cast: dtype");
+  FRX_CHECK_ARG(n >= 0, "cast: n<0");
+  if (n == 0) return FRX_OK;
+  FRX_CHECK_ARG(x && y, "cast: NULL pointer");
+  FRX_ENTER(device);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == FRX_F32) {
+    FRX_HIP(hipMemcpyAsync(y, x, sizeof(float) * (size_t)n, hipMemcpyDeviceToDevice, st));
+    return FRX_OK;
+  }
+  if (to_f32) hipLaunchKernelGGL(k_cast_to_f32<bf16_t>, dim3(ew_grid2(n)), dim3(256), 0, st, (long)n, (const bf16_t*)x, (float*)y);
+  else hipLaunchKernelGGL(k_cast_from_f32<bf16_t>, dim3(ew_grid2(n)), dim3(256), 0, st, (long)n, (const float*)x, (bf16_t*)y);
+  FRX_LAUNCH_CHECK();
+  return FRX_OK;
+}
+
+extern "C" int frx_colsum_f32(int device, frx_stream_t stream, int rows, int C, const float* x, float* out) {
+  FRX_CHECK_ARG(x && out && rows > 0 && C > 0, "colsum: bad args");
+  FRX_ENTER(device);
+  hipLaunchKernelGGL(k_colsum_f32, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, rows, C, x, out);
+  FRX_LAUNCH_CHECK();
+  return FRX_OK;
+}

@@ -19,6 +19,11 @@ class HeadDesc(C.Structure):
                 ("s", C.c_float), ("m", C.c_float), ("momentum", C.c_float), ("lamb", C.c_float)]
 
 
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("dtype", "N", "Hi", "Wi", "Ci", "Co", "R", "S", "stride", "pad",
+                                          "Ho", "Wo", "stem")]
+
+
 def library_path() -> str:
     return _LIB_PATH
 
@@ -36,6 +41,30 @@ _SIGS = {
                                _P, _P, _P, _P, _P, _P]),
     "frx_head_bwd": (C.c_int, [C.c_int, _P, C.POINTER(HeadDesc), _P, _P, _P, _P, _P, _P, C.c_size_t,
                                _P, _P, C.c_int]),
+    "frx_conv_stat_rows": (C.c_int, [C.POINTER(ConvDesc)]),
+    "frx_stem_padded_dims": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "frx_conv_fwd": (C.c_int, [C.c_int, _P, C.POINTER(ConvDesc), _P, _P, _P, _P, C.c_int, _P, _P, C.c_int, _P]),
+    "frx_conv_dgrad": (C.c_int, [C.c_int, _P, C.POINTER(ConvDesc), _P, _P, _P, _P]),
+    "frx_conv_wgrad": (C.c_int, [C.c_int, _P, C.POINTER(ConvDesc), _P, _P, _P, C.c_int, _P, _P]),
+    "frx_bn_finalize": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int64, _P, _P, C.c_float, C.c_float,
+                                  _P, _P, _P, _P, _P, _P]),
+    "frx_bn_eval_affine": (C.c_int, [C.c_int, _P, C.c_int, _P, _P, _P, _P, C.c_float, _P, _P]),
+    "frx_block_merge_fwd": (C.c_int, [C.c_int, _P, C.c_int, C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "frx_bn_bwd_partial_rows": (C.c_int, [C.c_int64, C.c_int]),
+    "frx_bn_bwd_reduce": (C.c_int, [C.c_int, _P, C.c_int, C.c_int64, C.c_int, _P, _P, _P, _P, _P, C.c_int,
+                                    _P, _P, _P, _P]),
+    "frx_bn_bwd_finalize": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int64, _P, _P, _P, _P, _P]),
+    "frx_bn_bwd_apply": (C.c_int, [C.c_int, _P, C.c_int, C.c_int64, C.c_int, _P, _P, _P, _P, _P, C.c_int,
+                                   _P, _P, _P, _P]),
+    "frx_stem_pool_fwd": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
+    "frx_stem_pool_bwd": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "frx_avgpool_fwd": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "frx_avgpool_bwd": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
+    "frx_sgd_step": (C.c_int, [C.c_int, _P, C.c_int64, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float]),
+    "frx_weight_prep": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "frx_input_prep": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
+    "frx_cast": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int64, _P, _P]),
+    "frx_colsum_f32": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, _P, _P]),
     "frx_pair_cosine": (C.c_int, [C.c_int, _P, _P, _P, C.c_int64, C.c_int32, _P]),
     "frx_threshold_count": (C.c_int, [C.c_int, _P, _P, _P, C.c_int64, C.c_float, _P]),
 }

@@ -108,3 +108,134 @@ def threshold_count(cos, same, thr):
     check(_lib.lib().frx_threshold_count(_dev(cos), _stream(cos), _p(cos), _p(same), cos.numel(), float(thr), _p(cnt)),
           "frx_threshold_count")
     return cnt
+
+
+# ------------------------------------------------------------------ backbone wrappers
+from ._lib import ConvDesc  # noqa: E402
+
+F32, BF16 = 0, 1
+TORCH_DT = {F32: torch.float32, BF16: torch.bfloat16}
+
+
+def conv_desc(dtype, N, Hi, Wi, Ci, Co, R, S, stride, pad, stem=False):
+    Ho = (Hi + 2 * pad - R) // stride + 1
+    Wo = (Wi + 2 * pad - S) // stride + 1
+    return ConvDesc(dtype, N, Hi, Wi, Ci, Co, R, S, stride, pad, Ho, Wo, int(stem))
+
+
+def stem_padded_dims(H, W):
+    hp, wp = C.c_int(0), C.c_int(0)
+    check(_lib.lib().frx_stem_padded_dims(H, W, C.byref(hp), C.byref(wp)), "frx_stem_padded_dims")
+    return hp.value, wp.value
+
+
+def conv_stat_rows(d):
+    r = _lib.lib().frx_conv_stat_rows(C.byref(d))
+    if r < 0:
+        raise FrxError("conv descriptor rejected: " + _lib.lib().frx_last_error().decode())
+    return r
+
+
+def conv_fwd(d, x, w, y, in_scale=None, in_shift=None, in_relu=False, bias=None, out_f32=False, stat_partial=None):
+    check(_lib.lib().frx_conv_fwd(_dev(x), _stream(x), C.byref(d), _p(x), _p(w), _p(in_scale), _p(in_shift),
+                                  int(in_relu), _p(bias), _p(y), int(out_f32), _p(stat_partial)), "frx_conv_fwd")
+    return y
+
+
+def conv_dgrad(d, dy, w_crsk, dx, addend=None):
+    check(_lib.lib().frx_conv_dgrad(_dev(dy), _stream(dy), C.byref(d), _p(dy), _p(w_crsk), _p(addend), _p(dx)),
+          "frx_conv_dgrad")
+    return dx
+
+
+def conv_wgrad(d, x, dy, dw, in_scale=None, in_shift=None, in_relu=False):
+    check(_lib.lib().frx_conv_wgrad(_dev(x), _stream(x), C.byref(d), _p(x), _p(in_scale), _p(in_shift),
+                                    int(in_relu), _p(dy), _p(dw)), "frx_conv_wgrad")
+    return dw
+
+
+def bn_finalize(partial, rows, Cc, count, gamma, beta, rmean, rvar, mean, invstd, scale, shift, eps=1e-5, momentum=0.1):
+    check(_lib.lib().frx_bn_finalize(_dev(partial), _stream(partial), _p(partial), rows, Cc, count, _p(gamma), _p(beta),
+                                     eps, momentum, _p(rmean), _p(rvar), _p(mean), _p(invstd), _p(scale), _p(shift)),
+          "frx_bn_finalize")
+
+
+def bn_eval_affine(gamma, beta, rmean, rvar, scale, shift, eps=1e-5):
+    check(_lib.lib().frx_bn_eval_affine(_dev(gamma), _stream(gamma), gamma.numel(), _p(gamma), _p(beta), _p(rmean),
+                                        _p(rvar), eps, _p(scale), _p(shift)), "frx_bn_eval_affine")
+
+
+def block_merge_fwd(dtype, rows, Cc, y3, s3, b3, idn, out, sd=None, bd=None):
+    check(_lib.lib().frx_block_merge_fwd(_dev(y3), _stream(y3), dtype, rows, Cc, _p(y3), _p(s3), _p(b3), _p(idn),
+                                         _p(sd), _p(bd), _p(out)), "frx_block_merge_fwd")
+    return out
+
+
+def bn_bwd_partial_rows(rows, Cc):
+    return _lib.lib().frx_bn_bwd_partial_rows(rows, Cc)
+
+
+def bn_bwd_reduce(dtype, rows, Cc, g, y, mean, invstd, partial, out=None, scale=None, shift=None, relu=False, dz_out=None):
+    check(_lib.lib().frx_bn_bwd_reduce(_dev(g), _stream(g), dtype, rows, Cc, _p(g), _p(y), _p(out), _p(scale),
+                                       _p(shift), int(relu), _p(mean), _p(invstd), _p(dz_out), _p(partial)),
+          "frx_bn_bwd_reduce")
+
+
+def bn_bwd_finalize(partial, nblk, Cc, count, gamma, invstd, dgamma, dbeta, coef):
+    check(_lib.lib().frx_bn_bwd_finalize(_dev(partial), _stream(partial), _p(partial), nblk, Cc, count, _p(gamma),
+                                         _p(invstd), _p(dgamma), _p(dbeta), _p(coef)), "frx_bn_bwd_finalize")
+
+
+def bn_bwd_apply(dtype, rows, Cc, g, y, mean, invstd, coef, dy, out=None, scale=None, shift=None, relu=False):
+    check(_lib.lib().frx_bn_bwd_apply(_dev(g), _stream(g), dtype, rows, Cc, _p(g), _p(y), _p(out), _p(scale),
+                                      _p(shift), int(relu), _p(mean), _p(invstd), _p(coef), _p(dy)), "frx_bn_bwd_apply")
+    return dy
+
+
+def stem_pool_fwd(dtype, N, H, W, Cc, y, scale, shift, out, argmax):
+    check(_lib.lib().frx_stem_pool_fwd(_dev(y), _stream(y), dtype, N, H, W, Cc, _p(y), _p(scale), _p(shift), _p(out),
+                                       _p(argmax)), "frx_stem_pool_fwd")
+
+
+def stem_pool_bwd(dtype, N, H, W, Cc, dout, argmax, dpost):
+    check(_lib.lib().frx_stem_pool_bwd(_dev(dout), _stream(dout), dtype, N, H, W, Cc, _p(dout), _p(argmax), _p(dpost)),
+          "frx_stem_pool_bwd")
+
+
+def avgpool_fwd(dtype, N, HW, Cc, x, out):
+    check(_lib.lib().frx_avgpool_fwd(_dev(x), _stream(x), dtype, N, HW, Cc, _p(x), _p(out)), "frx_avgpool_fwd")
+
+
+def avgpool_bwd(dtype, N, HW, Cc, dpool, dx):
+    check(_lib.lib().frx_avgpool_bwd(_dev(dpool), _stream(dpool), dtype, N, HW, Cc, _p(dpool), _p(dx)), "frx_avgpool_bwd")
+
+
+def sgd_step(p, g, buf, lr, momentum=0.9, weight_decay=5e-4, grad_scale=1.0, lr_dev=None):
+    check(_lib.lib().frx_sgd_step(_dev(p), _stream(p), p.numel(), _p(p), _p(g), _p(buf), _p(lr_dev), float(lr),
+                                  float(momentum), float(weight_decay), float(grad_scale)), "frx_sgd_step")
+
+
+def weight_prep(dtype, Co, RS, Ci, master, krsc=None, crsk=None):
+    check(_lib.lib().frx_weight_prep(_dev(master), _stream(master), dtype, Co, RS, Ci, _p(master), _p(krsc), _p(crsk)),
+          "frx_weight_prep")
+
+
+def input_prep(dtype, images, out):
+    if images.dtype == torch.uint8:
+        N, H, W, _ = images.shape
+        u8 = 1
+    else:
+        _chk(images, torch.float32, "images")
+        N, _, H, W = images.shape
+        u8 = 0
+    check(_lib.lib().frx_input_prep(_dev(images), _stream(images), dtype, N, H, W, _p(images), u8, _p(out)), "frx_input_prep")
+    return out
+
+
+def cast(dtype, x, y, to_f32):
+    check(_lib.lib().frx_cast(_dev(x), _stream(x), dtype, int(to_f32), x.numel(), _p(x), _p(y)), "frx_cast")
+    return y
+
+
+def colsum_f32(x, out):
+    check(_lib.lib().frx_colsum_f32(_dev(x), _stream(x), x.shape[0], x.shape[1], _p(x), _p(out)), "frx_colsum_f32")

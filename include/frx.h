@@ -103,6 +103,86 @@ int frx_pair_cosine(int device, frx_stream_t stream, const float* f1, const floa
 int frx_threshold_count(int device, frx_stream_t stream, const float* cos, const int64_t* same,
                         int64_t P, float thr, int32_t* correct);
 
+
+/* ---------------------------------------------------------------- backbone: convolutions
+ * Replace every nn.Conv2d / nn.Linear of the torchvision ResNet-50 the reference builds in
+ * utils/backbones.py:16-18 (forward: criterion.py:320; backward: model_utils.py:185).
+ * Activations are NHWC, weights K-contiguous: KRSC [Co][R][S][Ci] for forward / wgrad and CRSK
+ * [Ci][R][S][Co] for dgrad (frx_weight_prep makes both from the fp32 master copy).
+ * The previous layer's train-mode BatchNorm + ReLU is applied to the input while tiles are
+ * staged (in_scale / in_shift / in_relu), and the per-channel sum / sum-of-squares of the
+ * output needed by the NEXT BatchNorm come out of the epilogue (stat_partial). */
+typedef struct frx_conv_desc {
+  int32_t dtype;                 /* frx_dtype of activations and kernel-format weights */
+  int32_t N, Hi, Wi, Ci;         /* input  [N,Hi,Wi,Ci] */
+  int32_t Co, R, S, stride, pad; /* stride 1 or 2 */
+  int32_t Ho, Wo;                /* output [N,Ho,Wo,Co] */
+  int32_t stem;                  /* 1: 7x7 s2 conv on the zero-bordered NHWC4 image of frx_input_prep;
+                                    weights [Co][7][8][4] (tap 8 and channel 4 are zero) */
+} frx_conv_desc;
+
+/* rows of the stat_partial buffer ([rows][2][Co] floats) frx_conv_fwd writes for this layer */
+int frx_conv_stat_rows(const frx_conv_desc* d);
+int frx_stem_padded_dims(int Hi, int Wi, int* Hp, int* Wp);
+/* y = conv(f(x), w) [+ bias]; out_f32 stores y as fp32 (the fc layer feeding the head) */
+int frx_conv_fwd(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x, const void* w_krsc,
+                 const float* in_scale, const float* in_shift, int in_relu, const float* bias, void* y,
+                 int out_f32, float* stat_partial);
+/* dx = conv_transpose(dy, w) [+ addend]   (addend: the residual branch's gradient) */
+int frx_conv_dgrad(int device, frx_stream_t stream, const frx_conv_desc* d, const void* dy, const void* w_crsk,
+                   const void* addend, void* dx);
+/* dw (fp32 KRSC, accumulated) += f(x)^T dy */
+int frx_conv_wgrad(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x, const float* in_scale,
+                   const float* in_shift, int in_relu, const void* dy, float* dw);
+
+/* ---------------------------------------------------------------- backbone: BatchNorm / ReLU / residual / pools
+ * Replace nn.BatchNorm2d x53 (train: batch statistics + running-stat update, momentum 0.1, eps 1e-5;
+ * eval: running statistics), nn.ReLU, the residual add, MaxPool2d(3,2,1), AdaptiveAvgPool2d(1). */
+int frx_bn_finalize(int device, frx_stream_t stream, const float* partial, int rows, int C, int64_t count,
+                    const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                    float* running_var, float* mean, float* invstd, float* scale, float* shift);
+int frx_bn_eval_affine(int device, frx_stream_t stream, int C, const float* gamma, const float* beta,
+                       const float* running_mean, const float* running_var, float eps, float* scale, float* shift);
+/* out = relu(s3*y3 + b3 + idn),  idn = block input or sd*yd + bd (downsample branch) */
+int frx_block_merge_fwd(int device, frx_stream_t stream, int dtype, int64_t rows, int C, const void* y3,
+                        const float* s3, const float* b3, const void* idn, const float* sd, const float* bd,
+                        void* out);
+/* BatchNorm backward in three steps.  dz = g*mask with mask = (out>0) if out given, else
+ * (scale*y+shift>0) if relu, else 1.
+ *   reduce   -> partial [frx_bn_bwd_partial_rows][2][C] = (sum dz, sum dz*xhat); optional dz_out
+ *   finalize -> dgamma +=, dbeta +=, coef [3][C] = (gamma*invstd, sum dz / M, sum dz*xhat / M)
+ *   apply    -> dy = coef0 * (dz - coef1 - xhat*coef2) */
+int frx_bn_bwd_partial_rows(int64_t rows, int C);
+int frx_bn_bwd_reduce(int device, frx_stream_t stream, int dtype, int64_t rows, int C, const void* g, const void* y,
+                      const void* out, const float* scale, const float* shift, int relu, const float* mean,
+                      const float* invstd, void* dz_out, float* partial);
+int frx_bn_bwd_finalize(int device, frx_stream_t stream, const float* partial, int nblk, int C, int64_t count,
+                        const float* gamma, const float* invstd, float* dgamma, float* dbeta, float* coef);
+int frx_bn_bwd_apply(int device, frx_stream_t stream, int dtype, int64_t rows, int C, const void* g, const void* y,
+                     const void* out, const float* scale, const float* shift, int relu, const float* mean,
+                     const float* invstd, const float* coef, void* dy);
+int frx_stem_pool_fwd(int device, frx_stream_t stream, int dtype, int N, int H, int W, int C, const void* y,
+                      const float* scale, const float* shift, void* out, uint8_t* argmax);
+int frx_stem_pool_bwd(int device, frx_stream_t stream, int dtype, int N, int H, int W, int C, const void* dout,
+                      const uint8_t* argmax, void* dpost);
+int frx_avgpool_fwd(int device, frx_stream_t stream, int dtype, int N, int HW, int C, const void* x, void* out);
+int frx_avgpool_bwd(int device, frx_stream_t stream, int dtype, int N, int HW, int C, const void* dpool, void* dx);
+
+/* ---------------------------------------------------------------- optimiser / staging
+ * frx_sgd_step: optim.SGD(lr, momentum 0.9, weight_decay 5e-4) over ALL parameters in one launch
+ *   (model_utils.py:557,186).  lr_dev (optional device scalar) overrides lr, so a captured
+ *   hipGraph follows the CustomStepLR schedule (schedulers.py:3-14) without re-capture.
+ * frx_input_prep: ToTensor + Normalize(0.5,0.5) (model_utils.py:539-547) fused with the layout
+ *   change to the stem's zero-bordered NHWC4; `images` is fp32 NCHW in [-1,1] or uint8 NHWC. */
+int frx_sgd_step(int device, frx_stream_t stream, int64_t n, float* p, const float* g, float* buf,
+                 const float* lr_dev, float lr, float momentum, float weight_decay, float grad_scale);
+int frx_weight_prep(int device, frx_stream_t stream, int dtype, int Co, int RS, int Ci, const float* master_krsc,
+                    void* krsc, void* crsk);
+int frx_input_prep(int device, frx_stream_t stream, int dtype, int N, int H, int W, const void* images,
+                   int is_u8_nhwc, void* out);
+int frx_cast(int device, frx_stream_t stream, int dtype, int to_f32, int64_t n, const void* x, void* y);
+int frx_colsum_f32(int device, frx_stream_t stream, int rows, int C, const float* x, float* out);
+
 #ifdef __cplusplus
 }
 #endif

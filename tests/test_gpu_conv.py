@@ -1,0 +1,148 @@
+"""GPU parity of the implicit-GEMM convolution kernels (forward with fused BN+ReLU prologue and
+statistics epilogue, dgrad, wgrad, stem) through the C ABI against ATen CPU fp32 -- the oracle at
+the backbone boundary (torchvision itself is absent: parity unpinned upstream)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+# (Ci, Co, k, stride, Hi) -- the unique ResNet-50 shapes of SURVEY Appendix A, small batch
+SHAPES = [
+    (64, 64, 1, 1, 28), (64, 64, 3, 1, 28), (64, 256, 1, 1, 28), (256, 64, 1, 1, 28),
+    (128, 128, 3, 2, 28), (256, 512, 1, 2, 28), (512, 128, 1, 1, 14), (128, 128, 3, 1, 14),
+    (256, 256, 3, 2, 14), (1024, 256, 1, 1, 7), (256, 256, 3, 1, 7), (512, 512, 3, 2, 7),
+    (2048, 512, 1, 1, 4), (512, 512, 3, 1, 4), (512, 2048, 1, 1, 4),
+]
+
+
+def _tol(dtype):
+    from frx import ops
+    return (2e-4, 2e-4) if dtype == ops.F32 else (2e-2, 2e-2)
+
+
+def _mk(dtype, *shape, scale=1.0, seed=0):
+    from frx import ops
+    g = torch.Generator().manual_seed(seed)
+    t = (torch.randn(*shape, generator=g) * scale).to(ops.TORCH_DT[dtype])
+    return t
+
+
+def _close(got, ref, dtype, what):
+    rtol, atol = _tol(dtype)
+    ref = ref.float()
+    got = got.float().cpu()
+    scale = ref.abs().max().item() + 1e-12
+    err = (got - ref).abs().max().item()
+    assert err <= atol * scale + 1e-6, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
+
+
+@pytest.mark.parametrize("dtype", [0, 1], ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", SHAPES, ids=[f"{s[0]}x{s[1]}k{s[2]}s{s[3]}h{s[4]}" for s in SHAPES])
+def test_conv_fwd_dgrad_wgrad(dtype, shape):
+    from frx import ops
+    Ci, Co, k, stride, Hi = shape
+    N, pad = 3, k // 2
+    d = ops.conv_desc(dtype, N, Hi, Hi, Ci, Co, k, k, stride, pad)
+    x = _mk(dtype, N, Hi, Hi, Ci, seed=1)                       # NHWC
+    w = _mk(dtype, Co, k, k, Ci, scale=(Ci * k * k) ** -0.5, seed=2)   # KRSC
+    sc = (torch.rand(Ci, generator=torch.Generator().manual_seed(3)) + 0.5)
+    sc[::3] *= -1                                               # negative gammas occur in training
+    sh = torch.randn(Ci, generator=torch.Generator().manual_seed(4)) * 0.3
+    xd, wd = x.to(DEV), w.to(DEV)
+    # --- forward with prologue + stats
+    rows = ops.conv_stat_rows(d)
+    y = torch.empty(N, d.Ho, d.Wo, Co, dtype=x.dtype, device=DEV)
+    part = torch.zeros(rows, 2, Co, device=DEV)
+    ops.conv_fwd(d, xd, wd, y, in_scale=sc.to(DEV), in_shift=sh.to(DEV), in_relu=True, stat_partial=part)
+    xin = torch.relu(x.float() * sc + sh).to(x.dtype).float()   # what the kernel stages (rounded to T)
+    ref = F.conv2d(xin.permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), stride=stride, padding=pad)
+    ref = ref.permute(0, 2, 3, 1).contiguous()
+    _close(y, ref, dtype, "conv_fwd")
+    yq = y.float().cpu()
+    _close(part[:, 0].sum(0), yq.sum((0, 1, 2)), 0, "stat sum")
+    _close(part[:, 1].sum(0), (yq * yq).sum((0, 1, 2)), 0, "stat sumsq")
+    # --- forward without prologue
+    y2 = torch.empty_like(y)
+    ops.conv_fwd(d, xd, wd, y2)
+    ref2 = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), stride=stride, padding=pad)
+    _close(y2, ref2.permute(0, 2, 3, 1), dtype, "conv_fwd plain")
+    # --- dgrad (+ addend)
+    dy = _mk(dtype, N, d.Ho, d.Wo, Co, seed=5)
+    wt = torch.empty(Ci, k, k, Co, dtype=x.dtype, device=DEV)
+    wk = torch.empty(Co, k, k, Ci, dtype=x.dtype, device=DEV)
+    ops.weight_prep(dtype, Co, k * k, Ci, w.float().to(DEV).contiguous(), krsc=wk, crsk=wt)
+    assert torch.equal(wk.cpu(), w)
+    assert torch.equal(wt.cpu(), w.permute(3, 1, 2, 0).contiguous())
+    add = _mk(dtype, N, Hi, Hi, Ci, seed=6)
+    dx = torch.empty(N, Hi, Hi, Ci, dtype=x.dtype, device=DEV)
+    ops.conv_dgrad(d, dy.to(DEV), wt, dx, addend=add.to(DEV))
+    refdx = torch.nn.grad.conv2d_input((N, Ci, Hi, Hi), w.float().permute(0, 3, 1, 2), dy.float().permute(0, 3, 1, 2),
+                                       stride=stride, padding=pad).permute(0, 2, 3, 1) + add.float()
+    _close(dx, refdx, dtype, "conv_dgrad")
+    # --- wgrad with prologue (accumulates into dw)
+    dw = torch.full((Co, k, k, Ci), 0.5, device=DEV)
+    ops.conv_wgrad(d, xd, dy.to(DEV), dw, in_scale=sc.to(DEV), in_shift=sh.to(DEV), in_relu=True)
+    refdw = torch.nn.grad.conv2d_weight(xin.permute(0, 3, 1, 2), (Co, Ci, k, k), dy.float().permute(0, 3, 1, 2),
+                                        stride=stride, padding=pad).permute(0, 2, 3, 1) + 0.5
+    _close(dw, refdw, dtype, "conv_wgrad")
+
+
+@pytest.mark.parametrize("dtype", [0, 1], ids=["f32", "bf16"])
+def test_stem(dtype):
+    from frx import ops
+    N, H = 3, 112
+    g = torch.Generator().manual_seed(0)
+    img = torch.rand(N, 3, H, H, generator=g) * 2 - 1
+    w = torch.randn(64, 3, 7, 7, generator=g) * 0.05             # torchvision layout
+    hp, wp = ops.stem_padded_dims(H, H)
+    xin = torch.empty(N, hp, wp, 4, dtype=ops.TORCH_DT[dtype], device=DEV)
+    ops.input_prep(dtype, img.to(DEV), xin)
+    # uint8 path must give the same tensor as ToTensor+Normalize on the CPU
+    u8 = (torch.rand(N, H, H, 3, generator=g) * 255).to(torch.uint8)
+    xin8 = torch.empty_like(xin)
+    ops.input_prep(dtype, u8.to(DEV), xin8)
+    ref8 = ((u8.float() / 255 - 0.5) / 0.5).to(ops.TORCH_DT[dtype])
+    assert torch.equal(xin8[:, 3:3 + H, 3:3 + H, :3].cpu(), ref8)
+    assert xin8[:, :3].abs().sum() == 0 and xin8[..., 3].abs().sum() == 0
+    wk = torch.zeros(64, 7, 8, 4)
+    wk[:, :, :7, :3] = w.permute(0, 2, 3, 1)
+    wk = wk.to(ops.TORCH_DT[dtype])
+    d = ops.conv_desc(dtype, N, H, H, 3, 64, 7, 7, 2, 3, stem=True)
+    rows = ops.conv_stat_rows(d)
+    y = torch.empty(N, 56, 56, 64, dtype=xin.dtype, device=DEV)
+    part = torch.zeros(rows, 2, 64, device=DEV)
+    ops.conv_fwd(d, xin, wk.to(DEV), y, stat_partial=part)
+    imgq = img.to(ops.TORCH_DT[dtype]).float()
+    ref = F.conv2d(imgq, wk[:, :, :7, :3].float().permute(0, 3, 1, 2), stride=2, padding=3).permute(0, 2, 3, 1)
+    _close(y, ref, dtype, "stem fwd")
+    _close(part[:, 0].sum(0), y.float().cpu().sum((0, 1, 2)), 0, "stem stat")
+    dy = _mk(dtype, N, 56, 56, 64, seed=9)
+    dw = torch.zeros(64, 7, 8, 4, device=DEV)
+    ops.conv_wgrad(d, xin, dy.to(DEV), dw)
+    refdw = torch.nn.grad.conv2d_weight(imgq, (64, 3, 7, 7), dy.float().permute(0, 3, 1, 2), stride=2, padding=3)
+    _close(dw[:, :, :7, :3], refdw.permute(0, 2, 3, 1), dtype, "stem wgrad")
+
+
+@pytest.mark.parametrize("dtype", [0, 1], ids=["f32", "bf16"])
+def test_fc_as_conv(dtype):
+    """avgpool + Linear(2048, 512) with fp32 output and bias; ragged batch (N not a tile multiple)."""
+    from frx import ops
+    N = 37
+    x = _mk(dtype, N, 16, 2048, seed=1)
+    w = _mk(dtype, 512, 2048, scale=2048 ** -0.5, seed=2)
+    b = torch.randn(512, generator=torch.Generator().manual_seed(3))
+    pooled = torch.empty(N, 2048, dtype=x.dtype, device=DEV)
+    ops.avgpool_fwd(dtype, N, 16, 2048, x.to(DEV), pooled)
+    _close(pooled, x.float().mean(1), dtype, "avgpool")
+    d = ops.conv_desc(dtype, N, 1, 1, 2048, 512, 1, 1, 1, 0)
+    y = torch.empty(N, 512, device=DEV)
+    ops.conv_fwd(d, pooled, w.to(DEV), y, bias=b.to(DEV), out_f32=True)
+    ref = pooled.float().cpu() @ w.float().t() + b
+    _close(y, ref, dtype, "fc")
+    dpool = _mk(dtype, N, 2048, seed=4)
+    dx = torch.empty(N, 16, 2048, dtype=x.dtype, device=DEV)
+    ops.avgpool_bwd(dtype, N, 16, 2048, dpool.to(DEV), dx)
+    _close(dx, (dpool.float() / 16)[:, None, :].expand(N, 16, 2048), dtype, "avgpool bwd")
