@@ -1,0 +1,506 @@
+"""Execution plan for the ResNet-50 (torchvision v1.5 topology, fc -> 512) + margin-head
+training / embedding path on one MI355X, built on the libfrx C ABI.
+
+Everything is pre-allocated for a fixed per-GPU batch: parameters, gradients and SGD momentum
+live in three flat fp32 buffers (one fused optimiser launch, one contiguous all-reduce target);
+activations are NHWC in the compute dtype (bf16 = speed mode, fp32 = parity mode).
+A step only enqueues kernels on the current stream -- no allocation, no host sync -- so the
+whole step is hipGraph-capturable (torch.cuda.graph).
+
+Reference: backbone = torchvision resnet50 + nn.Linear(2048, 512) (main_code/utils/backbones.py:16-18),
+wrappers criterion.py:303-325 (and siblings), step model_utils.py:176-187, SGD :557.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import torch
+
+from . import ops
+from .ops import BF16, F32
+
+LAYERS = (3, 4, 6, 3)
+PLANES = (64, 128, 256, 512)
+FEATURE_DIM = 512
+BN_EPS, BN_MOMENTUM = 1e-5, 0.1
+
+
+@dataclass
+class ConvSpec:
+    name: str            # torchvision state-dict prefix, e.g. "layer1.0.conv1"
+    bn: str              # matching BatchNorm prefix, e.g. "layer1.0.bn1"
+    Ci: int
+    Co: int
+    k: int
+    stride: int
+    Hi: int
+    stem: bool = False
+    # filled by the engine
+    desc: object = None
+    w_off: int = 0       # offset of the fp32 master weight (KRSC) in the flat buffers
+    w_numel: int = 0
+    g_off: int = 0       # gamma offset;  beta = g_off + Co
+    bn_idx: int = 0      # index into the per-BN state table
+    wk: torch.Tensor = None
+    wt: torch.Tensor = None
+    y: torch.Tensor = None
+    stat_rows: int = 0
+
+    @property
+    def Ho(self):
+        return (self.Hi + 2 * (self.k // 2) - self.k) // self.stride + 1
+
+
+@dataclass
+class BlockSpec:
+    conv1: ConvSpec
+    conv2: ConvSpec
+    conv3: ConvSpec
+    down: ConvSpec | None
+    out: torch.Tensor = None
+
+
+def resnet50_specs(H=112):
+    stem = ConvSpec("conv1", "bn1", 3, 64, 7, 2, H, stem=True)
+    h = (stem.Ho + 2 - 3) // 2 + 1          # after max-pool
+    blocks, inpl = [], 64
+    for li, (n, planes) in enumerate(zip(LAYERS, PLANES), start=1):
+        for b in range(n):
+            stride = 2 if (b == 0 and li > 1) else 1
+            p = f"layer{li}.{b}"
+            c1 = ConvSpec(p + ".conv1", p + ".bn1", inpl, planes, 1, 1, h)
+            c2 = ConvSpec(p + ".conv2", p + ".bn2", planes, planes, 3, stride, h)
+            c3 = ConvSpec(p + ".conv3", p + ".bn3", planes, planes * 4, 1, 1, c2.Ho)
+            ds = None
+            if b == 0:
+                ds = ConvSpec(p + ".downsample.0", p + ".downsample.1", inpl, planes * 4, 1, stride, h)
+            blocks.append(BlockSpec(c1, c2, c3, ds))
+            inpl, h = planes * 4, c2.Ho
+    return stem, blocks, h
+
+
+class ResNet50Engine:
+    """Owns parameters, activations and scratch of the backbone; runs forward / backward."""
+
+    def __init__(self, batch, dtype=BF16, device="cuda:0", H=112, extra_params=0):
+        self.N, self.dtype, self.device, self.H = batch, dtype, torch.device(device), H
+        self.tdt = ops.TORCH_DT[dtype]
+        self.stem, self.blocks, self.h_final = resnet50_specs(H)
+        self.convs = [self.stem] + [c for b in self.blocks for c in (b.conv1, b.conv2, b.conv3, b.down) if c is not None]
+        # ---- flat parameter layout: [conv weights | bn gamma,beta | fc weight | fc bias | extra (head)]
+        off = 0
+        for c in self.convs:
+            c.w_numel = c.Co * 7 * 8 * 4 if c.stem else c.Co * c.k * c.k * c.Ci
+            c.w_off = off
+            off += c.w_numel
+        for i, c in enumerate(self.convs):
+            c.g_off, c.bn_idx = off, i
+            off += 2 * c.Co
+        self.fc_w_off = off
+        off += FEATURE_DIM * 2048
+        self.fc_b_off = off
+        off += FEATURE_DIM
+        self.backbone_numel = off
+        off = (off + 63) // 64 * 64
+        self.extra_off = off
+        self.n_params = (off + extra_params + 3) // 4 * 4
+        dev = self.device
+        self.params = torch.zeros(self.n_params, device=dev)
+        self.grads = torch.zeros(self.n_params, device=dev)
+        self.mom = torch.zeros(self.n_params, device=dev)
+        # ---- BN buffers: running stats + batch statistics / affine of the current step
+        ctot = sum(c.Co for c in self.convs)
+        self.bn_off = {}
+        o = 0
+        for c in self.convs:
+            self.bn_off[c.bn] = o
+            o += c.Co
+        self.running_mean = torch.zeros(ctot, device=dev)
+        self.running_var = torch.ones(ctot, device=dev)
+        self.num_batches_tracked = torch.zeros(len(self.convs), dtype=torch.int64, device=dev)
+        self.bn_mean = torch.zeros(ctot, device=dev)
+        self.bn_invstd = torch.zeros(ctot, device=dev)
+        self.bn_scale = torch.zeros(ctot, device=dev)
+        self.bn_shift = torch.zeros(ctot, device=dev)
+        # ---- kernel-format weights, activations
+        N = batch
+        for c in self.convs:
+            if c.stem:
+                c.desc = ops.conv_desc(dtype, N, H, H, 3, 64, 7, 7, 2, 3, stem=True)
+                c.wk = torch.zeros(64, 7, 8, 4, dtype=self.tdt, device=dev)
+            else:
+                c.desc = ops.conv_desc(dtype, N, c.Hi, c.Hi, c.Ci, c.Co, c.k, c.k, c.stride, c.k // 2)
+                c.wk = torch.zeros(c.Co, c.k, c.k, c.Ci, dtype=self.tdt, device=dev)
+                c.wt = torch.zeros(c.Ci, c.k, c.k, c.Co, dtype=self.tdt, device=dev)
+            c.stat_rows = ops.conv_stat_rows(c.desc)
+            c.y = torch.empty(N, c.Ho, c.Ho, c.Co, dtype=self.tdt, device=dev)
+        hp, wp = ops.stem_padded_dims(H, H)
+        self.xin = torch.zeros(N, hp, wp, 4, dtype=self.tdt, device=dev)
+        self.hpool = (self.stem.Ho + 2 - 3) // 2 + 1
+        self.pool_out = torch.empty(N, self.hpool, self.hpool, 64, dtype=self.tdt, device=dev)
+        self.pool_arg = torch.empty(N, self.hpool, self.hpool, 64, dtype=torch.uint8, device=dev)
+        for b in self.blocks:
+            b.out = torch.empty_like(b.conv3.y)
+        self.pooled = torch.empty(N, 2048, dtype=self.tdt, device=dev)
+        self.feats = torch.empty(N, FEATURE_DIM, device=dev)
+        self.fc_desc = ops.conv_desc(dtype, N, 1, 1, 2048, FEATURE_DIM, 1, 1, 1, 0)
+        self.fc_wk = torch.zeros(FEATURE_DIM, 2048, dtype=self.tdt, device=dev)
+        self.fc_wt = torch.zeros(2048, FEATURE_DIM, dtype=self.tdt, device=dev)
+        # ---- scratch
+        max_rows = max(c.stat_rows * c.Co for c in self.convs)
+        self.stat_partial = torch.empty(2 * max_rows, device=dev)
+        max_act = max(c.y.numel() for c in self.convs)
+        self.scratch = [torch.empty(max_act, dtype=self.tdt, device=dev) for _ in range(5)]
+        max_bp = max(ops.bn_bwd_partial_rows(c.y.numel() // c.Co, c.Co) * c.Co for c in self.convs)
+        self.bwd_partial = torch.empty(2 * max_bp, device=dev)
+        self.coef = torch.empty(3 * 2048, device=dev)
+        self.dfeat_t = torch.empty(N, FEATURE_DIM, dtype=self.tdt, device=dev)
+        self.lr_dev = torch.zeros(1, device=dev)
+        self.training = True
+        self._eval_affine_ready = False
+        self.reset_parameters()
+
+    # ------------------------------------------------------------------ parameter views
+    def w_master(self, c: ConvSpec):
+        shape = (c.Co, 7, 8, 4) if c.stem else (c.Co, c.k, c.k, c.Ci)
+        return self.params[c.w_off:c.w_off + c.w_numel].view(shape)
+
+    def w_grad(self, c: ConvSpec):
+        shape = (c.Co, 7, 8, 4) if c.stem else (c.Co, c.k, c.k, c.Ci)
+        return self.grads[c.w_off:c.w_off + c.w_numel].view(shape)
+
+    def gamma(self, c, buf=None):
+        return (self.params if buf is None else buf)[c.g_off:c.g_off + c.Co]
+
+    def beta(self, c, buf=None):
+        return (self.params if buf is None else buf)[c.g_off + c.Co:c.g_off + 2 * c.Co]
+
+    def fc_w(self, buf=None):
+        return (self.params if buf is None else buf)[self.fc_w_off:self.fc_w_off + FEATURE_DIM * 2048].view(FEATURE_DIM, 2048)
+
+    def fc_b(self, buf=None):
+        return (self.params if buf is None else buf)[self.fc_b_off:self.fc_b_off + FEATURE_DIM]
+
+    def extra(self, numel, buf=None):
+        return (self.params if buf is None else buf)[self.extra_off:self.extra_off + numel]
+
+    def _bn(self, t, c):
+        o = self.bn_off[c.bn]
+        return t[o:o + c.Co]
+
+    def reset_parameters(self, seed=None):
+        """torchvision init: conv kaiming_normal(fan_out, relu), BN gamma=1 beta=0, fc default Linear."""
+        g = torch.Generator(device="cpu")
+        if seed is not None:
+            g.manual_seed(seed)
+        for c in self.convs:
+            k = 7 if c.stem else c.k
+            std = math.sqrt(2.0 / (c.Co * k * k))
+            if c.stem:
+                w = torch.zeros(64, 7, 8, 4)
+                w[:, :, :7, :3] = torch.randn(64, 7, 7, 3, generator=g) * std
+            else:
+                w = torch.randn(c.Co, c.k, c.k, c.Ci, generator=g) * std
+            self.w_master(c).copy_(w)
+            self.gamma(c).fill_(1.0)
+            self.beta(c).zero_()
+        bound = 1.0 / math.sqrt(2048)
+        self.fc_w().copy_((torch.rand(FEATURE_DIM, 2048, generator=g) * 2 - 1) * bound)
+        self.fc_b().copy_((torch.rand(FEATURE_DIM, generator=g) * 2 - 1) * bound)
+        self.running_mean.zero_()
+        self.running_var.fill_(1.0)
+        self.num_batches_tracked.zero_()
+        self.mom.zero_()
+        self.sync_weights()
+
+    def sync_weights(self):
+        """fp32 master -> kernel-format copies (after an optimiser step or a state-dict load)."""
+        for c in self.convs:
+            if c.stem:
+                m = self.w_master(c)
+                m[:, :, 7, :] = 0          # the 8th tap / 4th channel exist only as padding
+                m[..., 3] = 0
+                ops.cast(self.dtype, m, c.wk, to_f32=False)
+            else:
+                ops.weight_prep(self.dtype, c.Co, c.k * c.k, c.Ci, self.w_master(c), krsc=c.wk, crsk=c.wt)
+        ops.weight_prep(self.dtype, FEATURE_DIM, 1, 2048, self.fc_w(), krsc=self.fc_wk, crsk=self.fc_wt)
+        self._eval_affine_ready = False
+
+    # ------------------------------------------------------------------ forward
+    def _conv_bn(self, c: ConvSpec, x, prev: ConvSpec | None):
+        """y = conv(f_prev(x)); then this layer's BN statistics -> scale/shift."""
+        kw = {}
+        if prev is not None:
+            kw = dict(in_scale=self._bn(self.bn_scale, prev), in_shift=self._bn(self.bn_shift, prev), in_relu=True)
+        if self.training:
+            ops.conv_fwd(c.desc, x, c.wk, c.y, stat_partial=self.stat_partial, **kw)
+            count = c.y.numel() // c.Co
+            ops.bn_finalize(self.stat_partial, c.stat_rows, c.Co, count, self.gamma(c), self.beta(c),
+                            self._bn(self.running_mean, c), self._bn(self.running_var, c),
+                            self._bn(self.bn_mean, c), self._bn(self.bn_invstd, c),
+                            self._bn(self.bn_scale, c), self._bn(self.bn_shift, c), BN_EPS, BN_MOMENTUM)
+        else:
+            ops.conv_fwd(c.desc, x, c.wk, c.y, **kw)
+        return c.y
+
+    def _prepare_eval_affine(self):
+        for c in self.convs:
+            ops.bn_eval_affine(self.gamma(c), self.beta(c), self._bn(self.running_mean, c),
+                               self._bn(self.running_var, c), self._bn(self.bn_scale, c), self._bn(self.bn_shift, c), BN_EPS)
+        self._eval_affine_ready = True
+
+    def forward(self, images):
+        """images: fp32 NCHW in [-1,1] or uint8 NHWC; returns feats [N,512] fp32 (engine-owned)."""
+        N, dt = self.N, self.dtype
+        if images.shape[0] != N:
+            raise ops.FrxError(f"engine was planned for batch {N}, got {images.shape[0]}")
+        if not self.training and not self._eval_affine_ready:
+            self._prepare_eval_affine()
+        if self.training:
+            self.num_batches_tracked += 1
+        ops.input_prep(dt, images, self.xin)
+        s = self.stem
+        self._conv_bn(s, self.xin, None)
+        ops.stem_pool_fwd(dt, N, s.Ho, s.Ho, 64, s.y, self._bn(self.bn_scale, s), self._bn(self.bn_shift, s),
+                          self.pool_out, self.pool_arg)
+        x = self.pool_out
+        for b in self.blocks:
+            self._conv_bn(b.conv1, x, None)
+            self._conv_bn(b.conv2, b.conv1.y, b.conv1)
+            self._conv_bn(b.conv3, b.conv2.y, b.conv2)
+            rows = b.out.numel() // b.conv3.Co
+            if b.down is not None:
+                self._conv_bn(b.down, x, None)
+                ops.block_merge_fwd(dt, rows, b.conv3.Co, b.conv3.y, self._bn(self.bn_scale, b.conv3),
+                                    self._bn(self.bn_shift, b.conv3), b.down.y, b.out,
+                                    sd=self._bn(self.bn_scale, b.down), bd=self._bn(self.bn_shift, b.down))
+            else:
+                ops.block_merge_fwd(dt, rows, b.conv3.Co, b.conv3.y, self._bn(self.bn_scale, b.conv3),
+                                    self._bn(self.bn_shift, b.conv3), x, b.out)
+            x = b.out
+        hw = self.h_final * self.h_final
+        ops.avgpool_fwd(dt, N, hw, 2048, x, self.pooled)
+        ops.conv_fwd(self.fc_desc, self.pooled, self.fc_wk, self.feats, bias=self.fc_b(), out_f32=True)
+        return self.feats
+
+    # ------------------------------------------------------------------ backward
+    def _bn_backward(self, c: ConvSpec, g, dy, out=None, relu=False, dz_out=None):
+        """g: upstream gradient w.r.t. the post-BN(-ReLU) tensor; writes dy (w.r.t. the conv output)."""
+        rows = c.y.numel() // c.Co
+        nblk = ops.bn_bwd_partial_rows(rows, c.Co)
+        sc, sh = (self._bn(self.bn_scale, c), self._bn(self.bn_shift, c)) if relu else (None, None)
+        mean, invstd = self._bn(self.bn_mean, c), self._bn(self.bn_invstd, c)
+        ops.bn_bwd_reduce(self.dtype, rows, c.Co, g, c.y, mean, invstd, self.bwd_partial, out=out, scale=sc, shift=sh,
+                          relu=relu, dz_out=dz_out)
+        ops.bn_bwd_finalize(self.bwd_partial, nblk, c.Co, rows, self.gamma(c), invstd, self.gamma(c, self.grads),
+                            self.beta(c, self.grads), self.coef)
+        src = dz_out if dz_out is not None else g
+        if dz_out is not None:
+            ops.bn_bwd_apply(self.dtype, rows, c.Co, src, c.y, mean, invstd, self.coef, dy)
+        else:
+            ops.bn_bwd_apply(self.dtype, rows, c.Co, src, c.y, mean, invstd, self.coef, dy, out=out, scale=sc, shift=sh, relu=relu)
+        return dy
+
+    def _like(self, buf, ref):
+        return buf[:ref.numel()].view(ref.shape)
+
+    def backward(self, dfeat):
+        """dfeat [N,512] fp32: gradient of the loss w.r.t. feats.  Accumulates into self.grads."""
+        N, dt = self.N, self.dtype
+        S = self.scratch
+        # fc
+        ops.cast(dt, dfeat, self.dfeat_t, to_f32=False)
+        ops.conv_wgrad(self.fc_desc, self.pooled, self.dfeat_t, self.fc_w(self.grads))
+        ops.colsum_f32(dfeat, self.fc_b(self.grads))
+        dpool = self._like(S[4], self.pooled)
+        ops.conv_dgrad(self.fc_desc, self.dfeat_t, self.fc_wt, dpool)
+        last = self.blocks[-1]
+        g = self._like(S[0], last.out)
+        ops.avgpool_bwd(dt, N, self.h_final * self.h_final, 2048, dpool, g)
+        gi = 0                                        # S[gi] holds g; S[1-gi] receives the next g
+        for bi in range(len(self.blocks) - 1, -1, -1):
+            b = self.blocks[bi]
+            x_in = self.blocks[bi - 1].out if bi > 0 else self.pool_out
+            c1, c2, c3, ds = b.conv1, b.conv2, b.conv3, b.down
+            dz = self._like(S[2], c3.y)               # g masked by the merge ReLU: feeds bn3 AND the identity
+            dy = self._like(S[3], c3.y)
+            self._bn_backward(c3, g, dy, out=b.out, dz_out=dz)
+            ops.conv_wgrad(c3.desc, c2.y, dy, self.w_grad(c3), in_scale=self._bn(self.bn_scale, c2),
+                           in_shift=self._bn(self.bn_shift, c2), in_relu=True)
+            dx3 = self._like(S[4], c2.y)
+            ops.conv_dgrad(c3.desc, dy, c3.wt, dx3)
+            dy2 = self._like(S[3], c2.y)
+            self._bn_backward(c2, dx3, dy2, relu=True)
+            ops.conv_wgrad(c2.desc, c1.y, dy2, self.w_grad(c2), in_scale=self._bn(self.bn_scale, c1),
+                           in_shift=self._bn(self.bn_shift, c1), in_relu=True)
+            dx2 = self._like(S[4], c1.y)
+            ops.conv_dgrad(c2.desc, dy2, c2.wt, dx2)
+            dy1 = self._like(S[3], c1.y)
+            self._bn_backward(c1, dx2, dy1, relu=True)
+            ops.conv_wgrad(c1.desc, x_in, dy1, self.w_grad(c1))
+            gnext = self._like(S[1 - gi], x_in)
+            if ds is not None:
+                dyd = self._like(S[4], ds.y)
+                self._bn_backward(ds, dz, dyd)
+                ops.conv_wgrad(ds.desc, x_in, dyd, self.w_grad(ds))
+                tmp = self._like(S[gi], x_in)         # g itself is dead once dz exists
+                ops.conv_dgrad(ds.desc, dyd, ds.wt, tmp)
+                ops.conv_dgrad(c1.desc, dy1, c1.wt, gnext, addend=tmp)
+            else:
+                ops.conv_dgrad(c1.desc, dy1, c1.wt, gnext, addend=dz)
+            g, gi = gnext, 1 - gi
+        # stem: max-pool -> ReLU/BN -> conv weight gradient (no image gradient)
+        s = self.stem
+        dpost = self._like(S[2], s.y)
+        ops.stem_pool_bwd(dt, N, s.Ho, s.Ho, 64, g, self.pool_arg, dpost)
+        dy0 = self._like(S[3], s.y)
+        self._bn_backward(s, dpost, dy0, relu=True)
+        ops.conv_wgrad(s.desc, self.xin, dy0, self.w_grad(s))
+        wg = self.w_grad(s)
+        wg[:, :, 7, :] = 0
+        wg[..., 3] = 0
+
+    # ------------------------------------------------------------------ optimiser
+    def zero_grad(self):
+        self.grads.zero_()
+
+    def sgd_step(self, lr=None, momentum=0.9, weight_decay=5e-4, grad_scale=1.0):
+        """lr=None: read the learning rate from self.lr_dev (graph-replay friendly)."""
+        ops.sgd_step(self.params, self.grads, self.mom, 0.0 if lr is None else lr, momentum, weight_decay, grad_scale,
+                     lr_dev=self.lr_dev if lr is None else None)
+        self.sync_weights()
+
+    # ------------------------------------------------------------------ torchvision-compatible state dict
+    def state_dict(self, prefix=""):
+        sd = {}
+        for i, c in enumerate(self.convs):
+            w = self.w_master(c)
+            w = w[:, :, :7, :3] if c.stem else w
+            sd[prefix + c.name + ".weight"] = w.permute(0, 3, 1, 2).contiguous().clone()
+            sd[prefix + c.bn + ".weight"] = self.gamma(c).clone()
+            sd[prefix + c.bn + ".bias"] = self.beta(c).clone()
+            sd[prefix + c.bn + ".running_mean"] = self._bn(self.running_mean, c).clone()
+            sd[prefix + c.bn + ".running_var"] = self._bn(self.running_var, c).clone()
+            sd[prefix + c.bn + ".num_batches_tracked"] = self.num_batches_tracked[i].clone()
+        sd[prefix + "fc.weight"] = self.fc_w().clone()
+        sd[prefix + "fc.bias"] = self.fc_b().clone()
+        return sd
+
+    def load_state_dict(self, sd, prefix="", strict=True):
+        missing = []
+
+        def get(k):
+            if prefix + k not in sd:
+                missing.append(prefix + k)
+                return None
+            return sd[prefix + k].to(self.device)
+        for i, c in enumerate(self.convs):
+            w = get(c.name + ".weight")
+            if w is not None:
+                w = w.float().permute(0, 2, 3, 1)
+                if c.stem:
+                    m = self.w_master(c)
+                    m.zero_()
+                    m[:, :, :7, :3] = w
+                else:
+                    self.w_master(c).copy_(w)
+            for key, dst in ((".weight", self.gamma(c)), (".bias", self.beta(c)),
+                             (".running_mean", self._bn(self.running_mean, c)),
+                             (".running_var", self._bn(self.running_var, c))):
+                v = get(c.bn + key)
+                if v is not None:
+                    dst.copy_(v.float())
+            v = get(c.bn + ".num_batches_tracked")
+            if v is not None:
+                self.num_batches_tracked[i] = v
+        for key, dst in (("fc.weight", self.fc_w()), ("fc.bias", self.fc_b())):
+            v = get(key)
+            if v is not None:
+                dst.copy_(v.float())
+        if strict and missing:
+            raise KeyError(f"missing keys in state_dict: {missing[:5]}{'...' if len(missing) > 5 else ''}")
+        self.sync_weights()
+        return missing
+
+
+HEAD_KINDS = {"arcface": ops.ARC, "cosface": ops.COS, "sphereface": ops.SPHERE, "curricular": ops.CURR}
+# (s, m) per head: main_code/utils/config.py:16-37.  SphereFace ignores s (criterion.py:119-123).
+HEAD_DEFAULTS = {ops.ARC: (64.0, 0.5), ops.COS: (64.0, 0.35), ops.SPHERE: (1.0, 2.0), ops.CURR: (64.0, 0.5)}
+
+
+class FaceEngine:
+    """Backbone + margin head + fused SGD: one training step = forward, CE, backward, update."""
+
+    def __init__(self, kind, num_classes, batch, dtype=BF16, device="cuda:0", s=None, m=None, momentum=0.01, seed=None):
+        self.kind = HEAD_KINDS[kind] if isinstance(kind, str) else kind
+        self.C, self.N = num_classes, batch
+        ds, dm = HEAD_DEFAULTS[self.kind]
+        self.s, self.m = (ds if s is None else s), (dm if m is None else m)
+        self.w_cd = self.kind in (ops.ARC, ops.SPHERE)
+        self.net = ResNet50Engine(batch, dtype, device, extra_params=num_classes * FEATURE_DIM)
+        self.device = self.net.device
+        self.head = ops.HeadContext(self.kind, batch, FEATURE_DIM, num_classes, self.s, self.m, momentum, device=self.device)
+        self.t = torch.zeros(1, device=self.device)          # CurricularFace buffer `t` (criterion.py:517)
+        self.sphere_iter = 0                                 # SphereFace.iter (criterion.py:33): python int
+        self.dfeat = torch.empty(batch, FEATURE_DIM, device=self.device)
+        self.last = None
+        self.world = 1
+        self.allreduce = None                                # callable(flat fp32 grads) for data parallel
+        self.ty_allreduce = None
+        self.reset_head(seed)
+
+    # head weight views, in the reference's own layouts
+    def head_w(self, buf=None):
+        shape = (self.C, FEATURE_DIM) if self.w_cd else (FEATURE_DIM, self.C)
+        return self.net.extra(self.C * FEATURE_DIM, buf).view(shape)
+
+    def reset_head(self, seed=None):
+        g = torch.Generator(device="cpu")
+        if seed is not None:
+            g.manual_seed(seed + 1)
+        C, D = self.C, FEATURE_DIM
+        if self.kind in (ops.ARC, ops.SPHERE):      # xavier_uniform_ on [C,D] (criterion.py:244,37)
+            bound = math.sqrt(6.0 / (C + D))
+            w = (torch.rand(C, D, generator=g) * 2 - 1) * bound
+        elif self.kind == ops.COS:                   # uniform(-1,1).renorm_(2,1,1e-5).mul_(1e5) (criterion.py:152)
+            w = (torch.rand(D, C, generator=g) * 2 - 1).renorm_(2, 1, 1e-5).mul_(1e5)
+        else:                                        # normal(std=0.01) (criterion.py:514)
+            w = torch.randn(D, C, generator=g) * 0.01
+        self.head_w().copy_(w)
+        self.t.zero_()
+        self.sphere_iter = 0
+
+    def _lamb(self):
+        # criterion.py:58-60: iter += 1; lamb = max(5, 1000 * (1 + 0.12*iter)^-1)
+        self.sphere_iter += 1
+        return max(5.0, 1000.0 * (1 + 0.12 * self.sphere_iter) ** (-1))
+
+    def forward_loss(self, images, labels, want_logits=False):
+        feats = self.net.forward(images)
+        lamb = self._lamb() if self.kind == ops.SPHERE else 0.0
+        self.last = ops.head_forward(self.head, feats, self.head_w(), labels, state_t=self.t, lamb=lamb,
+                                     want_logits=want_logits, ty_allreduce=self.ty_allreduce)
+        self.last["feats"] = feats
+        return self.last
+
+    def backward(self, labels, gout=None):
+        ops.head_backward(self.head, self.net.feats, self.head_w(), labels, state_t=self.t, gout=gout,
+                          dx=self.dfeat, dw=self.head_w(self.net.grads), accumulate_dw=False)
+        self.net.backward(self.dfeat)
+
+    def train_step(self, images, labels, lr=None):
+        """zero_grad -> forward -> CE -> backward -> [all-reduce] -> SGD (model_utils.py:176-187)."""
+        self.net.training = True
+        self.net.zero_grad()
+        out = self.forward_loss(images, labels)
+        self.backward(labels)
+        if self.allreduce is not None:
+            self.allreduce(self.net.grads)
+        self.net.sgd_step(lr, grad_scale=1.0 / self.world)
+        return out
+
+    @torch.no_grad()
+    def embed(self, images):
+        self.net.training = False
+        return self.net.forward(images)
