@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/s of one ArcFace ResNet-50 TRAINING step (forward + CE + backward +
+SGD) at 112x112, bf16, batch 256 per GPU, 10 575 identities -- BASELINE.json configs[1].
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One process per GPU (RCCL over xGMI via torch.distributed "nccl").  Rank 0 prints ONE JSON line.
+  value        whole-job images/s, inputs resident in HBM, max-over-ranks wall time of K steps
+  roofline     the dominant kernel (by device time) timed per launch with HIP events on its own stream
+               in a separate eager pass after the timed region (the timed region replays a hipGraph,
+               which leaves no place for per-kernel events); achieved = algorithmic FLOPs / duration
+  cpu_baseline the CPU oracle (oracle/resnet50.py, "port") on this box's host cores:
+               BASELINE.json configs[0] (ArcFace R50, 100 identities, bs 32, fp32), a few steps
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "face-recognition-models_amd"))
+
+import torch  # noqa: E402
+
+FLOP_PER_IMG_BACKBONE = 6.4025e9        # fwd + dgrad + wgrad, no image gradient
+PEAK_BF16_TFLOPS = 2516.6               # 256 CU x 2.4 GHz x 4096 FLOP/clk/CU dense (MI355X_MICROARCH.md: ~2.5 PF)
+PEAK_HBM_GBS = 8000.0
+
+
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def host_threads():
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))          # a 1-GPU box's CPU share
+
+
+def cpu_baseline(threads, max_seconds=25.0):
+    from oracle import heads as H
+    from oracle.resnet50 import FaceNet, make_sgd, train_step
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    net = FaceNet(H.ARC, 100)
+    opt = make_sgd(net, 0.1)
+    g = torch.Generator().manual_seed(1234)
+    images = torch.rand(32, 3, 112, 112, generator=g) * 2 - 1
+    labels = torch.randint(0, 100, (32,), generator=g)
+    train_step(net, opt, images, labels)                       # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while n < 2 or (time.perf_counter() - t0 < max_seconds / 2 and n < 10):
+        train_step(net, opt, images, labels)
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": round(32 * n / dt, 2), "unit": "images/s", "cores": threads, "kind": "port",
+            "sample": f"{n} timed steps (+1 warm-up) of BASELINE configs[0]: ArcFace ResNet-50, 100 identities, bs=32, "
+                      f"fp32, torch CPU oracle, {dt:.1f}s"}
+
+
+def kernel_pass(eng, images, labels, steps=3):
+    """Per-launch HIP-event timing of the GEMM-class kernels over `steps` eager steps."""
+    from frx import ops
+    eng.train_step(images, labels)
+    torch.cuda.synchronize()
+    ops.PROFILER = []
+    for _ in range(steps):
+        eng.train_step(images, labels)
+    torch.cuda.synchronize()
+    rec, ops.PROFILER = ops.PROFILER, None
+    agg = {}
+    for label, flops, e0, e1 in rec:
+        a = agg.setdefault(label, [0.0, 0.0, 0])
+        a[0] += e0.elapsed_time(e1) * 1e-3
+        a[1] += flops
+        a[2] += 1
+    return agg
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--classes", type=int, default=10575)
+    ap.add_argument("--head", default="arcface")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from frx import ddp, engine as E, ops
+    dt = ops.BF16 if args.dtype == "bf16" else ops.F32
+    eng = E.FaceEngine(args.head, args.classes, args.batch, dtype=dt, device=dev, seed=0)   # same init on all ranks
+    if world > 1:
+        ddp.attach(eng)
+    g = torch.Generator().manual_seed(1234 + rank)
+    nb = 4
+    batches = [((torch.rand(args.batch, 3, 112, 112, generator=g) * 2 - 1).to(dev),
+                torch.randint(0, args.classes, (args.batch,), generator=g).to(dev)) for _ in range(nb)]
+    images = torch.empty_like(batches[0][0])
+    labels = torch.empty_like(batches[0][1])
+    eng.net.lr_dev.fill_(0.1)                                  # run.sh:16 / parse_args default lr
+
+    def feed(i):
+        images.copy_(batches[i % nb][0])
+        labels.copy_(batches[i % nb][1])
+
+    log(f"engine ready: {eng.net.n_params} parameters, batch {args.batch}, world {world}")
+    use_graph = (not args.no_graph) and world == 1
+    graph = None
+    if use_graph:
+        side = torch.cuda.Stream()
+        feed(0)
+        with torch.cuda.stream(side):
+            eng.train_step(images, labels)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = eng.train_step(images, labels)
+
+    def step(i):
+        feed(i)
+        if graph is not None:
+            graph.replay()
+            return out
+        return eng.train_step(images, labels)
+
+    log("graph captured" if graph is not None else "eager mode")
+    for i in range(args.warmup):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        o = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt_s = time.perf_counter() - t0
+    loss = float(o["loss"].item())
+    log(f"timed region done: {dt_s / args.steps * 1e3:.3f} ms/step")
+    tmax = torch.tensor([dt_s], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt_s = float(tmax.item())
+
+    result = None
+    if rank == 0:
+        ips = world * args.batch * args.steps / dt_s
+        flop_img = FLOP_PER_IMG_BACKBONE + 6.0 * 512 * args.classes
+        agg = kernel_pass(eng, images, labels) if world == 1 else {}
+        roof = None
+        if agg:
+            label, (secs, flops, launches) = max(agg.items(), key=lambda kv: kv[1][0])
+            ach = flops / secs / 1e12
+            peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+            roof = {"bound": "mfma", "kernel": label, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(ach / peak, 4), "traffic": None,
+                    "avg_launch_us": round(secs / launches * 1e6, 2), "launches_per_step": launches // 3,
+                    "per_kernel": {k: {"ms_per_step": round(v[0] / 3 * 1e3, 3), "tflops": round(v[1] / v[0] / 1e12, 1),
+                                       "launches_per_step": v[2] // 3} for k, v in sorted(agg.items())}}
+        cpu = None
+        if world == 1 and not args.no_cpu_baseline:
+            log("cpu baseline (oracle, configs[0]) ...")
+            cpu = cpu_baseline(host_threads())
+        result = {
+            "metric": "images/sec (112x112) ArcFace ResNet-50 train",
+            "value": round(ips, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(dt_s / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": f"{args.head} ResNet-50 (torchvision v1.5 topology, fc->512), {args.classes}-class head, "
+                                   f"bs={args.batch}/GPU, 112x112, fwd+CE+bwd+SGD(momentum 0.9, wd 5e-4), "
+                                   f"random-init weights, BASELINE configs[1]",
+                       "global_batch": world * args.batch, "parallelism": f"dp{world}",
+                       "hip_graph": bool(graph is not None), "final_loss": round(loss, 4)},
+            "step_mfma_frac": round(ips * flop_img / (world * PEAK_BF16_TFLOPS * 1e12), 4),
+            "roofline": roof, "cpu_baseline": cpu,
+        }
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

@@ -22,19 +22,39 @@ template <typename T> struct Vec16 {
 // ---------------------------------------------------------------- BN forward statistics
 // partial [rows][2][C] (sum, sum of squares from the conv epilogue) -> batch mean / biased var,
 // scale = gamma*invstd, shift = beta - mean*scale, running stats (momentum 0.1, unbiased var).
+// column sums of a [rows][2][C] partial buffer: 64 channels x 4 row-lanes per block, coalesced
+__device__ __forceinline__ void partial_colsum(const float* __restrict__ partial, int rows, int C,
+                                               double& s, double& q, int& c) {
+  __shared__ double red[2][4][64];
+  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  c = blockIdx.x * 64 + cl;
+  double a = 0.0, b = 0.0;
+  if (c < C) {
+    float a0 = 0.f, b0 = 0.f;
+    int r = rl, n = 0;
+    for (; r < rows; r += 4) {
+      a0 += partial[((long)r * 2 + 0) * C + c];
+      b0 += partial[((long)r * 2 + 1) * C + c];
+      if (++n == 16) { a += (double)a0; b += (double)b0; a0 = 0.f; b0 = 0.f; n = 0; }   // short fp32 runs, fp64 total
+    }
+    a += (double)a0; b += (double)b0;
+  }
+  red[0][rl][cl] = a; red[1][rl][cl] = b;
+  __syncthreads();
+  s = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
+  q = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+}
+
 __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ partial, int rows, int C,
                                                      double count, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps, float momentum,
                                                      float* __restrict__ rmean, float* __restrict__ rvar,
                                                      float* __restrict__ mean_o, float* __restrict__ invstd_o,
                                                      float* __restrict__ scale_o, float* __restrict__ shift_o) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, q = 0.0;
-  for (int r = 0; r < rows; ++r) {
-    s += (double)partial[((long)r * 2 + 0) * C + c];
-    q += (double)partial[((long)r * 2 + 1) * C + c];
-  }
+  double s, q;
+  int c;
+  partial_colsum(partial, rows, C, s, q, c);
+  if (threadIdx.x >= 64 || c >= C) return;
   const double mean = s / count;
   double var = q / count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -65,24 +85,44 @@ __global__ __launch_bounds__(256) void k_bn_eval_affine(int C, const float* __re
 
 // ---------------------------------------------------------------- residual merge (forward)
 // out = relu(s3*y3 + b3 + idn)            idn = block input, or sd*yd + bd for a downsample branch
+// Row-major [rows][C] sweeps: a thread keeps ONE 16-byte channel group and walks down the rows, so
+// the per-channel constants sit in registers instead of being re-fetched per element.
+struct RowWalk {
+  int groups, gpb, rpp, tg, trow;
+  __device__ __forceinline__ RowWalk(int C, int V) {
+    groups = C / V;
+    gpb = groups < 256 ? groups : 256;
+    rpp = 256 / gpb;
+    tg = threadIdx.x % gpb;
+    trow = threadIdx.x / gpb;
+  }
+};
+
 template <typename T>
-__global__ __launch_bounds__(256) void k_merge_fwd(long nvec, int C, const T* __restrict__ y3,
+__global__ __launch_bounds__(256) void k_merge_fwd(long rows, int C, const T* __restrict__ y3,
                                                    const float* __restrict__ s3, const float* __restrict__ b3,
                                                    const T* __restrict__ idn, const float* __restrict__ sd,
                                                    const float* __restrict__ bd, T* __restrict__ out) {
   constexpr int V = Vec16<T>::N;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
-    const int c = (int)((i * V) % C);
-    Vec16<T> a, b, o;
-    a.raw = reinterpret_cast<const uint4*>(y3)[i];
-    b.raw = reinterpret_cast<const uint4*>(idn)[i];
+  const RowWalk w(C, V);
+  for (int g0 = 0; g0 < w.groups; g0 += w.gpb) {
+    const int grp = g0 + w.tg, c = grp * V;
+    float ks[V], kb[V], ds[V], db[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-      float id = b.get(j);
-      if (sd) id = fmaf(id, sd[c + j], bd[c + j]);
-      o.set(j, fmaxf(fmaf(a.get(j), s3[c + j], b3[c + j]) + id, 0.f));
+      ks[j] = s3[c + j]; kb[j] = b3[c + j];
+      ds[j] = sd ? sd[c + j] : 1.f; db[j] = sd ? bd[c + j] : 0.f;
     }
-    reinterpret_cast<uint4*>(out)[i] = o.raw;
+    for (long r = (long)blockIdx.x * w.rpp + w.trow; r < rows; r += (long)gridDim.x * w.rpp) {
+      const long i = r * w.groups + grp;
+      Vec16<T> a, b, o;
+      a.raw = reinterpret_cast<const uint4*>(y3)[i];
+      b.raw = reinterpret_cast<const uint4*>(idn)[i];
+#pragma unroll
+      for (int j = 0; j < V; ++j)
+        o.set(j, fmaxf(fmaf(a.get(j), ks[j], kb[j]) + fmaf(b.get(j), ds[j], db[j]), 0.f));
+      reinterpret_cast<uint4*>(out)[i] = o.raw;
+    }
   }
 }
 
@@ -158,13 +198,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict
                                                          const float* __restrict__ invstd,
                                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                          float* __restrict__ coef) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  double a = 0.0, b = 0.0;
-  for (int r = 0; r < nblk; ++r) {
-    a += (double)partial[((long)r * 2 + 0) * C + c];
-    b += (double)partial[((long)r * 2 + 1) * C + c];
-  }
+  double a, b;
+  int c;
+  partial_colsum(partial, nblk, C, a, b, c);
+  if (threadIdx.x >= 64 || c >= C) return;
   if (dbeta) dbeta[c] += (float)a;
   if (dgamma) dgamma[c] += (float)b;
   coef[c] = gamma[c] * invstd[c];
@@ -174,7 +211,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict
 
 // dy = k1 * (dz - c1 - xhat*c2);  dz = g*mask with the same mask rule as the reduce kernel
 template <typename T>
-__global__ __launch_bounds__(256) void k_bn_bwd_apply(long nvec, int C, const T* __restrict__ g,
+__global__ __launch_bounds__(256) void k_bn_bwd_apply(long rows, int C, const T* __restrict__ g,
                                                       const T* __restrict__ y, const T* __restrict__ out,
                                                       const float* __restrict__ scale,
                                                       const float* __restrict__ shift, int relu,
@@ -182,23 +219,33 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(long nvec, int C, const T*
                                                       const float* __restrict__ invstd,
                                                       const float* __restrict__ coef, T* __restrict__ dy) {
   constexpr int V = Vec16<T>::N;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (long)gridDim.x * 256) {
-    const int c = (int)((i * V) % C);
-    Vec16<T> vg, vy, vo, vd;
-    vg.raw = reinterpret_cast<const uint4*>(g)[i];
-    vy.raw = reinterpret_cast<const uint4*>(y)[i];
-    if (out) vo.raw = reinterpret_cast<const uint4*>(out)[i];
+  const RowWalk w(C, V);
+  for (int g0 = 0; g0 < w.groups; g0 += w.gpb) {
+    const int grp = g0 + w.tg, c = grp * V;
+    float k1[V], c1[V], c2[V], mu[V], is[V], sc[V], sh[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-      const float yy = vy.get(j);
-      bool on = true;
-      if (out) on = vo.get(j) > 0.f;
-      else if (relu) on = fmaf(yy, scale[c + j], shift[c + j]) > 0.f;
-      const float dz = on ? vg.get(j) : 0.f;
-      const float xh = (yy - mean[c + j]) * invstd[c + j];
-      vd.set(j, coef[c + j] * (dz - coef[C + c + j] - xh * coef[2 * C + c + j]));
+      k1[j] = coef[c + j]; c1[j] = coef[C + c + j]; c2[j] = coef[2 * C + c + j];
+      mu[j] = mean[c + j]; is[j] = invstd[c + j];
+      sc[j] = (relu && !out) ? scale[c + j] : 1.f; sh[j] = (relu && !out) ? shift[c + j] : 0.f;
     }
-    reinterpret_cast<uint4*>(dy)[i] = vd.raw;
+    for (long r = (long)blockIdx.x * w.rpp + w.trow; r < rows; r += (long)gridDim.x * w.rpp) {
+      const long i = r * w.groups + grp;
+      Vec16<T> vg, vy, vo, vd;
+      vg.raw = reinterpret_cast<const uint4*>(g)[i];
+      vy.raw = reinterpret_cast<const uint4*>(y)[i];
+      if (out) vo.raw = reinterpret_cast<const uint4*>(out)[i];
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const float yy = vy.get(j);
+        bool on = true;
+        if (out) on = vo.get(j) > 0.f;
+        else if (relu) on = fmaf(yy, sc[j], sh[j]) > 0.f;
+        const float dz = on ? vg.get(j) : 0.f;
+        vd.set(j, k1[j] * (dz - c1[j] - (yy - mu[j]) * is[j] * c2[j]));
+      }
+      reinterpret_cast<uint4*>(dy)[i] = vd.raw;
+    }
   }
 }
 
@@ -209,30 +256,40 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_pool_fwd(int N, int H, int W, int C, const T* __restrict__ y,
                                                   const float* __restrict__ scale, const float* __restrict__ shift,
                                                   T* __restrict__ out, uint8_t* __restrict__ argmax) {
-  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  const long total = (long)N * Ho * Wo * C;
+  constexpr int V = Vec16<T>::N;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1, G = C / V;
+  const long total = (long)N * Ho * Wo * G;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int c = (int)(i % C);
-    long p = i / C;
+    const int g = (int)(i % G);
+    long p = i / G;
     const int ow = (int)(p % Wo); p /= Wo;
     const int oh = (int)(p % Ho);
     const int n = (int)(p / Ho);
-    const float sc = scale[c], sh = shift[c];
-    float best = -INFINITY;
-    int arg = 0;
+    const int c = g * V;
+    float sc[V], sh[V], best[V];
+    int arg[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) { sc[j] = scale[c + j]; sh[j] = shift[c + j]; best[j] = -INFINITY; arg[j] = 0; }
 #pragma unroll
     for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
       for (int kw = 0; kw < 3; ++kw) {
         const int h = oh * 2 - 1 + kh, w = ow * 2 - 1 + kw;
         if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
-          float v = fmaxf(fmaf(load_as_float<T>(y, (((long)n * H + h) * W + w) * C + c), sc, sh), 0.f);
-          v = (float)(T)v;
-          if (v > best) { best = v; arg = kh * 3 + kw; }
+          Vec16<T> v, q;
+          v.raw = *reinterpret_cast<const uint4*>(y + (((long)n * H + h) * W + w) * C + c);
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            q.set(j, fmaxf(fmaf(v.get(j), sc[j], sh[j]), 0.f));   // round to T like the stored output
+            const float f = q.get(j);
+            if (f > best[j]) { best[j] = f; arg[j] = kh * 3 + kw; }
+          }
         }
       }
-    out[i] = (T)best;
-    argmax[i] = (uint8_t)arg;
+    Vec16<T> o;
+#pragma unroll
+    for (int j = 0; j < V; ++j) { o.set(j, best[j]); argmax[i * V + j] = (uint8_t)arg[j]; }
+    reinterpret_cast<uint4*>(out)[i] = o.raw;
   }
 }
 
@@ -240,27 +297,36 @@ __global__ __launch_bounds__(256) void k_pool_fwd(int N, int H, int W, int C, co
 template <typename T>
 __global__ __launch_bounds__(256) void k_pool_bwd(int N, int H, int W, int C, const T* __restrict__ dout,
                                                   const uint8_t* __restrict__ argmax, T* __restrict__ dpost) {
-  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
-  const long total = (long)N * H * W * C;
+  constexpr int V = Vec16<T>::N;
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1, G = C / V;
+  const long total = (long)N * H * W * G;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int c = (int)(i % C);
-    long p = i / C;
+    const int g = (int)(i % G);
+    long p = i / G;
     const int w = (int)(p % W); p /= W;
     const int h = (int)(p % H);
     const int n = (int)(p / H);
-    float acc = 0.f;
-    // windows oh with oh*2-1 <= h <= oh*2+1
+    float acc[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) acc[j] = 0.f;
     for (int oh = (h >> 1); oh <= ((h + 1) >> 1); ++oh) {
       if (oh >= Ho) continue;
       const int kh = h - (oh * 2 - 1);
       for (int ow = (w >> 1); ow <= ((w + 1) >> 1); ++ow) {
         if (ow >= Wo) continue;
-        const int kw = w - (ow * 2 - 1);
-        const long o = (((long)n * Ho + oh) * Wo + ow) * C + c;
-        if (argmax[o] == kh * 3 + kw) acc += load_as_float<T>(dout, o);
+        const int code = kh * 3 + (w - (ow * 2 - 1));
+        const long o = ((((long)n * Ho + oh) * Wo + ow) * G + g);
+        Vec16<T> d;
+        d.raw = reinterpret_cast<const uint4*>(dout)[o];
+        const uint8_t* am = argmax + o * V;
+#pragma unroll
+        for (int j = 0; j < V; ++j) if (am[j] == code) acc[j] += d.get(j);
       }
     }
-    dpost[i] = (T)acc;
+    Vec16<T> r;
+#pragma unroll
+    for (int j = 0; j < V; ++j) r.set(j, acc[j]);
+    reinterpret_cast<uint4*>(dpost)[i] = r.raw;
   }
 }
 
@@ -287,6 +353,16 @@ __global__ __launch_bounds__(256) void k_avgpool_bwd(int N, int HW, int C, const
   }
 }
 
+// grid for the RowWalk kernels: enough blocks to cover the rows, capped at 16 per CU
+static inline int row_grid(long rows, int C, int V) {
+  const int groups = C / V;
+  const int rpp = groups < 256 ? 256 / groups : 1;
+  long b = (rows + rpp - 1) / rpp;
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
 static inline int ew_grid(long work_items) {
   long b = (work_items + 255) / 256;
   if (b > 256 * 16) b = 256 * 16;
@@ -297,6 +373,7 @@ static inline int ew_grid(long work_items) {
 }  // namespace frx
 using namespace frx;
 
+static inline bool frx_groups_ok(int groups) { return groups >= 256 ? groups % 256 == 0 : (groups > 0 && 256 % groups == 0); }
 #define FRX_DT_CHECK(dt) FRX_CHECK_ARG((dt) == FRX_F32 || (dt) == FRX_BF16, "unsupported dtype %d", (dt))
 #define FRX_VEC(dt) ((dt) == FRX_BF16 ? 8 : 4)
 
@@ -308,7 +385,7 @@ extern "C" int frx_bn_finalize(int device, frx_stream_t stream, const float* par
   FRX_CHECK_ARG(rows > 0 && C > 0 && count > 0, "bn_finalize: bad sizes");
   FRX_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats come together");
   FRX_ENTER(device);
-  hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, partial, rows, C,
+  hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, partial, rows, C,
                      (double)count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
   FRX_LAUNCH_CHECK();
   return FRX_OK;
@@ -330,14 +407,15 @@ extern "C" int frx_block_merge_fwd(int device, frx_stream_t stream, int dtype, i
                                    const float* bd, void* out) {
   FRX_DT_CHECK(dtype);
   FRX_CHECK_ARG(y3 && s3 && b3 && idn && out && rows > 0 && C % FRX_VEC(dtype) == 0, "block_merge_fwd: bad args");
+  FRX_CHECK_ARG(frx_groups_ok(C / FRX_VEC(dtype)), "block_merge_fwd: C=%d must give a power-of-two number of 16-byte groups", C);
   FRX_CHECK_ARG((sd == nullptr) == (bd == nullptr), "block_merge_fwd: sd/bd come together");
   FRX_ENTER(device);
-  const long nvec = rows * C / FRX_VEC(dtype);
+  const int grid = row_grid(rows, C, FRX_VEC(dtype));
   if (dtype == FRX_BF16)
-    hipLaunchKernelGGL(k_merge_fwd<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, nvec, C,
+    hipLaunchKernelGGL(k_merge_fwd<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (long)rows, C,
                        (const bf16_t*)y3, s3, b3, (const bf16_t*)idn, sd, bd, (bf16_t*)out);
   else
-    hipLaunchKernelGGL(k_merge_fwd<float>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, nvec, C,
+    hipLaunchKernelGGL(k_merge_fwd<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (long)rows, C,
                        (const float*)y3, s3, b3, (const float*)idn, sd, bd, (float*)out);
   FRX_LAUNCH_CHECK();
   return FRX_OK;
@@ -379,7 +457,7 @@ extern "C" int frx_bn_bwd_finalize(int device, frx_stream_t stream, const float*
                                    float* dbeta, float* coef) {
   FRX_CHECK_ARG(partial && gamma && invstd && coef && nblk > 0 && C > 0 && count > 0, "bn_bwd_finalize: bad args");
   FRX_ENTER(device);
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, partial, nblk, C,
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, partial, nblk, C,
                      (double)count, gamma, invstd, dgamma, dbeta, coef);
   FRX_LAUNCH_CHECK();
   return FRX_OK;
@@ -390,15 +468,16 @@ extern "C" int frx_bn_bwd_apply(int device, frx_stream_t stream, int dtype, int6
                                 const float* mean, const float* invstd, const float* coef, void* dy) {
   FRX_DT_CHECK(dtype);
   FRX_CHECK_ARG(g && y && mean && invstd && coef && dy && rows > 0 && C % FRX_VEC(dtype) == 0, "bn_bwd_apply: bad args");
+  FRX_CHECK_ARG(frx_groups_ok(C / FRX_VEC(dtype)), "bn_bwd_apply: C=%d must give a power-of-two number of 16-byte groups", C);
   FRX_CHECK_ARG(out || !relu || (scale && shift), "bn_bwd_apply: ReLU mask needs out or scale/shift");
   FRX_ENTER(device);
-  const long nvec = rows * C / FRX_VEC(dtype);
+  const int grid = row_grid(rows, C, FRX_VEC(dtype));
   if (dtype == FRX_BF16)
-    hipLaunchKernelGGL(k_bn_bwd_apply<bf16_t>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, nvec, C,
+    hipLaunchKernelGGL(k_bn_bwd_apply<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (long)rows, C,
                        (const bf16_t*)g, (const bf16_t*)y, (const bf16_t*)out, scale, shift, relu, mean, invstd, coef,
                        (bf16_t*)dy);
   else
-    hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(ew_grid(nvec)), dim3(256), 0, (hipStream_t)stream, nvec, C,
+    hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (long)rows, C,
                        (const float*)g, (const float*)y, (const float*)out, scale, shift, relu, mean, invstd, coef,
                        (float*)dy);
   FRX_LAUNCH_CHECK();
@@ -408,9 +487,9 @@ extern "C" int frx_bn_bwd_apply(int device, frx_stream_t stream, int dtype, int6
 extern "C" int frx_stem_pool_fwd(int device, frx_stream_t stream, int dtype, int N, int H, int W, int C,
                                  const void* y, const float* scale, const float* shift, void* out, uint8_t* argmax) {
   FRX_DT_CHECK(dtype);
-  FRX_CHECK_ARG(y && scale && shift && out && argmax && N > 0 && H > 1 && W > 1 && C > 0, "stem_pool_fwd: bad args");
+  FRX_CHECK_ARG(y && scale && shift && out && argmax && N > 0 && H > 1 && W > 1 && C > 0 && C % FRX_VEC(dtype) == 0, "stem_pool_fwd: bad args");
   FRX_ENTER(device);
-  const long total = (long)N * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * C;
+  const long total = (long)N * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * C / FRX_VEC(dtype);
   if (dtype == FRX_BF16)
     hipLaunchKernelGGL(k_pool_fwd<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, N, H, W, C,
                        (const bf16_t*)y, scale, shift, (bf16_t*)out, argmax);
@@ -424,9 +503,9 @@ extern "C" int frx_stem_pool_fwd(int device, frx_stream_t stream, int dtype, int
 extern "C" int frx_stem_pool_bwd(int device, frx_stream_t stream, int dtype, int N, int H, int W, int C,
                                  const void* dout, const uint8_t* argmax, void* dpost) {
   FRX_DT_CHECK(dtype);
-  FRX_CHECK_ARG(dout && argmax && dpost && N > 0 && H > 1 && W > 1 && C > 0, "stem_pool_bwd: bad args");
+  FRX_CHECK_ARG(dout && argmax && dpost && N > 0 && H > 1 && W > 1 && C > 0 && C % FRX_VEC(dtype) == 0, "stem_pool_bwd: bad args");
   FRX_ENTER(device);
-  const long total = (long)N * H * W * C;
+  const long total = (long)N * H * W * C / FRX_VEC(dtype);
   if (dtype == FRX_BF16)
     hipLaunchKernelGGL(k_pool_bwd<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, N, H, W, C,
                        (const bf16_t*)dout, argmax, (bf16_t*)dpost);

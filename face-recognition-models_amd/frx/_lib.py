@@ -76,6 +76,9 @@ def load_library(path: str | None = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
+    # torch bundles its own HIP runtime; it must be in the process first so libfrx.so binds to the
+    # SAME runtime (two runtimes in one process do not share devices, streams or allocations)
+    import torch  # noqa: F401
     p = path or _LIB_PATH
     if not os.path.exists(p):
         raise FrxError(f"native library not built: {p} is missing -- run "

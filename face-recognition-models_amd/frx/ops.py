@@ -11,6 +11,37 @@ from ._lib import FrxError, HeadDesc, check
 
 ARC, COS, SPHERE, CURR = 0, 1, 2, 3
 
+# Optional per-launch timing (bench.py roofline leg): when PROFILER is a list, the GEMM-class entry
+# points bracket their launch with events on the current stream and append
+# (kernel label, algorithmic FLOPs, start event, end event).
+PROFILER = None
+
+
+def _timed(label, flops, dev_tensor, fn):
+    if PROFILER is None:
+        return fn()
+    e0 = torch.cuda.Event(enable_timing=True)
+    e1 = torch.cuda.Event(enable_timing=True)
+    st = torch.cuda.current_stream(dev_tensor.device)
+    e0.record(st)
+    r = fn()
+    e1.record(st)
+    PROFILER.append((label, flops, e0, e1))
+    return r
+
+
+def _igemm_tile(M, ncol):
+    """mirror of pick_tile() in csrc/conv.hip (only used to label profiled launches)"""
+    if ncol <= 64:
+        return 128, 64
+    if ((M + 127) // 128) * ((ncol + 127) // 128) < 384:
+        return 64, 64
+    return 128, 128
+
+
+def _dt_name(dt):
+    return "bf16" if dt == 1 else "f32"
+
 
 def _dev(t: torch.Tensor) -> int:
     if not t.is_cuda:
@@ -136,21 +167,33 @@ def conv_stat_rows(d):
     return r
 
 
+def conv_flops(d):
+    """algorithmic FLOPs of one conv pass (2 x MACs; the stem counts its real 7x7x3 taps)"""
+    k = 147 if d.stem else d.R * d.S * d.Ci
+    return 2.0 * d.N * d.Ho * d.Wo * d.Co * k
+
+
 def conv_fwd(d, x, w, y, in_scale=None, in_shift=None, in_relu=False, bias=None, out_f32=False, stat_partial=None):
-    check(_lib.lib().frx_conv_fwd(_dev(x), _stream(x), C.byref(d), _p(x), _p(w), _p(in_scale), _p(in_shift),
-                                  int(in_relu), _p(bias), _p(y), int(out_f32), _p(stat_partial)), "frx_conv_fwd")
+    bm, bn = _igemm_tile(d.N * d.Ho * d.Wo, d.Co)
+    _timed(f"k_igemm<{_dt_name(d.dtype)},{bm},{bn}>", conv_flops(d), x, lambda: check(
+        _lib.lib().frx_conv_fwd(_dev(x), _stream(x), C.byref(d), _p(x), _p(w), _p(in_scale), _p(in_shift),
+                                int(in_relu), _p(bias), _p(y), int(out_f32), _p(stat_partial)), "frx_conv_fwd"))
     return y
 
 
 def conv_dgrad(d, dy, w_crsk, dx, addend=None):
-    check(_lib.lib().frx_conv_dgrad(_dev(dy), _stream(dy), C.byref(d), _p(dy), _p(w_crsk), _p(addend), _p(dx)),
-          "frx_conv_dgrad")
+    bm, bn = _igemm_tile(d.N * d.Hi * d.Wi, d.Ci)
+    _timed(f"k_igemm<{_dt_name(d.dtype)},{bm},{bn}>", conv_flops(d), dy, lambda: check(
+        _lib.lib().frx_conv_dgrad(_dev(dy), _stream(dy), C.byref(d), _p(dy), _p(w_crsk), _p(addend), _p(dx)),
+        "frx_conv_dgrad"))
     return dx
 
 
 def conv_wgrad(d, x, dy, dw, in_scale=None, in_shift=None, in_relu=False):
-    check(_lib.lib().frx_conv_wgrad(_dev(x), _stream(x), C.byref(d), _p(x), _p(in_scale), _p(in_shift),
-                                    int(in_relu), _p(dy), _p(dw)), "frx_conv_wgrad")
+    bt = 64 if (d.Co <= 64 or (32 if d.stem else d.Ci) <= 64) else 128
+    _timed(f"k_wgrad<{_dt_name(d.dtype)},{bt}>", conv_flops(d), x, lambda: check(
+        _lib.lib().frx_conv_wgrad(_dev(x), _stream(x), C.byref(d), _p(x), _p(in_scale), _p(in_shift),
+                                  int(in_relu), _p(dy), _p(dw)), "frx_conv_wgrad"))
     return dw
 
 
