@@ -17,6 +17,7 @@ static TileCfg pick_tile(long M, int Ncol) {
 
 template <typename T>
 static int launch_igemm(hipStream_t st, ConvArgs a) {
+  FRX_CHECK_ARG(a.Ncol % 8 == 0, "igemm: output channel count %d must be a multiple of 8", a.Ncol);
   const TileCfg c = pick_tile(a.M, a.Ncol);
   a.tilesM = cdiv(a.M, c.bm);
   a.tilesN = cdiv(a.Ncol, c.bn);

@@ -47,6 +47,10 @@ struct ConvArgs {
 // h = {0,2,3,1}, makes every 16-lane service group hit 16 distinct slots.
 __device__ __forceinline__ int swz64(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }
 
+// Weight-fragment row permutation: fragment j, MFMA row fr  ->  channel offset inside the wave's
+// N range, chosen so fragments (2a, 2a+1) give a lane 8 consecutive channels (see the epilogue).
+__device__ __forceinline__ int chan_of(int j, int fr) { return 32 * (j >> 1) + 8 * (fr >> 2) + 4 * (j & 1) + (fr & 3); }
+
 template <typename T>
 __device__ __forceinline__ uint4 bn_relu_vec(uint4 raw, const float* __restrict__ sc,
                                              const float* __restrict__ sh, int relu) {
@@ -208,78 +212,136 @@ __global__ __launch_bounds__(256) void k_igemm(ConvArgs a) {
     }
 #pragma unroll
     for (int j = 0; j < FN; ++j) {
-      const int row = wn * WTN + j * 16 + fr;
+      const int row = wn * WTN + chan_of(j, fr);
       fb[j] = *reinterpret_cast<const uint4*>(Bs + (row * 4 + (fq ^ swz64(row))) * 16);
     }
+    // Operands are swapped (weights first): D[row = channel][col = pixel], so a lane ends up with
+    // 4 CONSECUTIVE channels of one pixel per fragment -- contiguous in NHWC memory.
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         if constexpr (sizeof(T) == 2) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&fa[i]),
-                                                              *reinterpret_cast<bf16x8*>(&fb[j]), acc[i][j], 0, 0, 0);
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&fb[j]),
+                                                              *reinterpret_cast<bf16x8*>(&fa[i]), acc[i][j], 0, 0, 0);
         } else {
           const float* pa = reinterpret_cast<const float*>(&fa[i]);
           const float* pb = reinterpret_cast<const float*>(&fb[j]);
 #pragma unroll
           for (int q = 0; q < 4; ++q)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[q], pb[q], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(pb[q], pa[q], acc[i][j], 0, 0, 0);
         }
       }
     if (kc + 1 < nk) store_chunk(cur ^ 1);
     __syncthreads();
   }
 
-  // ---- epilogue.  C/D map: col = lane&15, row = (lane>>4)*4 + reg
-  float csum[FN], csq[FN];
+  // ---- epilogue.  C/D map: col = lane&15 (pixel), row = (lane>>4)*4 + reg (channel slot).
+  // Fragment pair (2a, 2a+1) holds, for this lane, channels 32a + 8*fq + [0..8): one 16-byte
+  // (bf16) or two 16-byte (fp32) stores per pixel instead of 8 scalar ones.
+  float csum[FN][4], csq[FN][4];
 #pragma unroll
-  for (int j = 0; j < FN; ++j) { csum[j] = 0.f; csq[j] = 0.f; }
+  for (int j = 0; j < FN; ++j)
 #pragma unroll
-  for (int i = 0; i < FM; ++i)
+    for (int r = 0; r < 4; ++r) { csum[j][r] = 0.f; csq[j][r] = 0.f; }
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int n = n0 + wn * WTN + j * 16 + fr;
-      const float bias = (a.bias && n < a.Ncol) ? a.bias[n] : 0.f;
+  for (int a2 = 0; a2 < FN / 2; ++a2) {
+    const int nb = n0 + wn * WTN + 32 * a2 + 8 * fq;          // first of this lane's 8 channels
+    const bool nok = nb < a.Ncol;                              // Ncol % 8 == 0 (checked on the host)
+    float bias[8];
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * WTM + i * 16 + fq * 4 + r;
-        if (m < a.M && n < a.Ncol) {
-          float v = acc[i][j][r] + bias;
-          const long o = (long)m * a.Ncol + n;
-          if (a.out_f32) {
-            if (a.addend) v += reinterpret_cast<const float*>(a.addend)[o];
-            reinterpret_cast<float*>(a.Y)[o] = v;
-          } else {
-            if (a.addend) v += load_as_float<T>(a.addend, o);
-            const T t = (T)v;
-            reinterpret_cast<T*>(a.Y)[o] = t;
-            v = (float)t;       // statistics of the values the next layer will read
+    for (int e = 0; e < 8; ++e) bias[e] = (a.bias && nok) ? a.bias[nb + e] : 0.f;
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int m = m0 + wm * WTM + i * 16 + fr;
+      if (m < a.M && nok) {
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * a2 + (e >> 2)][e & 3] + bias[e];
+        const long o = (long)m * a.Ncol + nb;
+        if (a.out_f32) {
+          if (a.addend) {
+            const float4 p0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.addend) + o);
+            const float4 p1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.addend) + o + 4);
+            v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w; v[4] += p1.x; v[5] += p1.y; v[6] += p1.z; v[7] += p1.w;
           }
-          csum[j] += v;
-          csq[j] += v * v;
+          float* yo = reinterpret_cast<float*>(a.Y) + o;
+          *reinterpret_cast<float4*>(yo) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(yo + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else if constexpr (sizeof(T) == 4) {
+          if (a.addend) {
+            const float4 p0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.addend) + o);
+            const float4 p1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.addend) + o + 4);
+            v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w; v[4] += p1.x; v[5] += p1.y; v[6] += p1.z; v[7] += p1.w;
+          }
+          float* yo = reinterpret_cast<float*>(a.Y) + o;
+          *reinterpret_cast<float4*>(yo) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(yo + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+          if (a.addend) {
+            const uint4 praw = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.addend) + o);
+            const bf16x8 p = *reinterpret_cast<const bf16x8*>(&praw);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += (float)p[e];
+          }
+          bf16x8 t;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { t[e] = (bf16_t)v[e]; v[e] = (float)t[e]; }   // stats of what the next layer reads
+          *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.Y) + o) = *reinterpret_cast<uint4*>(&t);
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { csum[2 * a2 + (e >> 2)][e & 3] += v[e]; csq[2 * a2 + (e >> 2)][e & 3] += v[e] * v[e]; }
+      }
+    }
+  }
+  if (a.stat_partial) {
+    // Reduce over the 16 pixel-lanes with a halving butterfly: after the steps, lane fr holds the
+    // total of value index (fr % NV), NV = FN*4 values per lane.
+    constexpr int NV = FN * 4;
+    float vs[NV], vq[NV];
+#pragma unroll
+    for (int j = 0; j < FN; ++j)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { vs[j * 4 + r] = csum[j][r]; vq[j * 4 + r] = csq[j][r]; }
+    int nv = NV;
+#pragma unroll
+    for (int bit = 8; bit >= 1; bit >>= 1) {
+      if (nv > bit) {        // halve: keep the half selected by this lane's bit, add the partner's
+        const bool up = (fr & bit) != 0;
+        const int h = nv / 2;
+#pragma unroll
+        for (int e = 0; e < NV / 2; ++e) {
+          if (e < h) {
+            const float ks = up ? vs[e + h] : vs[e], ss = up ? vs[e] : vs[e + h];
+            const float kq = up ? vq[e + h] : vq[e], sq = up ? vq[e] : vq[e + h];
+            vs[e] = ks + __shfl_xor(ss, bit, 64);
+            vq[e] = kq + __shfl_xor(sq, bit, 64);
+          }
+        }
+        nv = h;
+      } else {               // fewer values than lanes on this bit: plain all-reduce step
+#pragma unroll
+        for (int e = 0; e < NV; ++e) {
+          if (e < nv) { vs[e] += __shfl_xor(vs[e], bit, 64); vq[e] += __shfl_xor(vq[e], bit, 64); }
         }
       }
     }
-  if (a.stat_partial) {
-    float* red = reinterpret_cast<float*>(smem);   // [2][WM][BN]; K loop ended with a barrier
-#pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      float s = csum[j], q = csq[j];
-      s += __shfl_xor(s, 16, 64); s += __shfl_xor(s, 32, 64);
-      q += __shfl_xor(q, 16, 64); q += __shfl_xor(q, 32, 64);
-      if (fq == 0) {
-        red[(0 * WM + wm) * BN + wn * WTN + j * 16 + fr] = s;
-        red[(1 * WM + wm) * BN + wn * WTN + j * 16 + fr] = q;
-      }
+    // lane fr now owns value index vi = fr % NV  ->  fragment j = vi>>2, reg r = vi&3
+    float* red = reinterpret_cast<float*>(smem);   // [2][WM][BN]; the K loop ended with a barrier
+    if (fr < NV) {
+      const int j = fr >> 2, r = fr & 3;
+      const int col = wn * WTN + 32 * (j >> 1) + 8 * fq + 4 * (j & 1) + r;
+      red[(0 * WM + wm) * BN + col] = vs[0];
+      red[(1 * WM + wm) * BN + col] = vq[0];
     }
     __syncthreads();
     for (int t = tid; t < 2 * BN; t += 256) {
       const int which = t / BN, col = t % BN;
       if (n0 + col < a.Ncol) {
-        float s = 0.f;
+        float sum = 0.f;
 #pragma unroll
-        for (int w = 0; w < WM; ++w) s += red[(which * WM + w) * BN + col];
-        a.stat_partial[((long)mt * 2 + which) * a.Ncol + n0 + col] = s;
+        for (int w = 0; w < WM; ++w) sum += red[(which * WM + w) * BN + col];
+        a.stat_partial[((long)mt * 2 + which) * a.Ncol + n0 + col] = sum;
       }
     }
   }

@@ -1,0 +1,43 @@
+"""Diagnostic: per-launch time of every GEMM-class kernel in one training step (HIP events, eager)."""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "face-recognition-models_amd"))
+import torch
+from frx import engine as E, ops
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
+eng = E.FaceEngine("arcface", 10575, N, dtype=ops.BF16, device="cuda:0", seed=0)
+g = torch.Generator().manual_seed(0)
+images = (torch.rand(N, 3, 112, 112, generator=g) * 2 - 1).cuda(); labels = torch.randint(0, 10575, (N,), generator=g).cuda()
+# wrap to capture descriptors
+calls = []
+orig = ops._timed
+def timed(label, flops, t, fn):
+    calls.append(label); return orig(label, flops, t, fn)
+ops._timed = timed
+descs = []
+for name in ("conv_fwd", "conv_dgrad", "conv_wgrad"):
+    f = getattr(ops, name)
+    def mk(f, name):
+        def w(d, *a, **k):
+            descs.append((name, d)); return f(d, *a, **k)
+        return w
+    setattr(ops, name, mk(f, name))
+eng.train_step(images, labels, 0.1); eng.train_step(images, labels, 0.1)
+torch.cuda.synchronize()
+REP = 5
+acc = None
+for _ in range(REP):
+    descs.clear(); ops.PROFILER = []
+    eng.train_step(images, labels, 0.1)
+    torch.cuda.synchronize()
+    ts = [e0.elapsed_time(e1) * 1e3 for (_, _, e0, e1) in ops.PROFILER]
+    acc = ts if acc is None else [min(a, b) for a, b in zip(acc, ts)]
+rec = ops.PROFILER; ops.PROFILER = None
+tot = {}
+print(f"{'op':11s} {'kernel':24s} {'Ci':>5s} {'Co':>5s} k s {'Hi':>3s} {'us':>8s} {'TF/s':>7s} {'GB/s':>7s}")
+for (name, d), (label, flops, _, _), us in zip(descs, rec, acc):
+    M_out = d.N * d.Ho * d.Wo; M_in = d.N * d.Hi * d.Wi
+    byt = 2 * (M_in * (4 if d.stem else d.Ci) + M_out * d.Co + d.Co * d.R * d.S * d.Ci)
+    print(f"{name:11s} {label:24s} {d.Ci:5d} {d.Co:5d} {d.R} {d.stride} {d.Hi:3d} {us:8.1f} {flops/us/1e6:7.1f} {byt/us/1e3:7.0f}")
+    tot[name] = tot.get(name, 0) + us
+print({k: round(v / 1e3, 3) for k, v in tot.items()}, "ms")
