@@ -22,27 +22,37 @@ template <typename T> struct Vec16 {
 // ---------------------------------------------------------------- BN forward statistics
 // partial [rows][2][C] (sum, sum of squares from the conv epilogue) -> batch mean / biased var,
 // scale = gamma*invstd, shift = beta - mean*scale, running stats (momentum 0.1, unbiased var).
-// column sums of a [rows][2][C] partial buffer: 64 channels x 4 row-lanes per block, coalesced
+// Column sums of a [rows][2][C] partial buffer.  The buffer was just written by up to thousands of
+// blocks, so this is latency-bound: 16 channels x 16 row-lanes per block with 4 independent
+// accumulators per lane keeps many loads in flight; fp32 partial runs are short, the total is fp64.
 __device__ __forceinline__ void partial_colsum(const float* __restrict__ partial, int rows, int C,
                                                double& s, double& q, int& c) {
-  __shared__ double red[2][4][64];
-  const int cl = threadIdx.x & 63, rl = threadIdx.x >> 6;
-  c = blockIdx.x * 64 + cl;
+  __shared__ double red[2][16][16];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  c = blockIdx.x * 16 + cl;
   double a = 0.0, b = 0.0;
   if (c < C) {
-    float a0 = 0.f, b0 = 0.f;
-    int r = rl, n = 0;
-    for (; r < rows; r += 4) {
-      a0 += partial[((long)r * 2 + 0) * C + c];
-      b0 += partial[((long)r * 2 + 1) * C + c];
-      if (++n == 16) { a += (double)a0; b += (double)b0; a0 = 0.f; b0 = 0.f; n = 0; }   // short fp32 runs, fp64 total
+    int r = rl;
+    for (; r + 48 < rows; r += 64) {
+      const float a0 = partial[((long)r * 2 + 0) * C + c], b0 = partial[((long)r * 2 + 1) * C + c];
+      const float a1 = partial[((long)(r + 16) * 2 + 0) * C + c], b1 = partial[((long)(r + 16) * 2 + 1) * C + c];
+      const float a2 = partial[((long)(r + 32) * 2 + 0) * C + c], b2 = partial[((long)(r + 32) * 2 + 1) * C + c];
+      const float a3 = partial[((long)(r + 48) * 2 + 0) * C + c], b3 = partial[((long)(r + 48) * 2 + 1) * C + c];
+      a += (double)((a0 + a1) + (a2 + a3));
+      b += (double)((b0 + b1) + (b2 + b3));
     }
-    a += (double)a0; b += (double)b0;
+    for (; r < rows; r += 16) {
+      a += (double)partial[((long)r * 2 + 0) * C + c];
+      b += (double)partial[((long)r * 2 + 1) * C + c];
+    }
   }
   red[0][rl][cl] = a; red[1][rl][cl] = b;
   __syncthreads();
-  s = red[0][0][cl] + red[0][1][cl] + red[0][2][cl] + red[0][3][cl];
-  q = red[1][0][cl] + red[1][1][cl] + red[1][2][cl] + red[1][3][cl];
+  s = 0.0; q = 0.0;
+  if (threadIdx.x < 16) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { s += red[0][i][cl]; q += red[1][i][cl]; }
+  }
 }
 
 __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ partial, int rows, int C,
@@ -54,7 +64,7 @@ __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ p
   double s, q;
   int c;
   partial_colsum(partial, rows, C, s, q, c);
-  if (threadIdx.x >= 64 || c >= C) return;
+  if (threadIdx.x >= 16 || c >= C) return;
   const double mean = s / count;
   double var = q / count - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -201,7 +211,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict
   double a, b;
   int c;
   partial_colsum(partial, nblk, C, a, b, c);
-  if (threadIdx.x >= 64 || c >= C) return;
+  if (threadIdx.x >= 16 || c >= C) return;
   if (dbeta) dbeta[c] += (float)a;
   if (dgamma) dgamma[c] += (float)b;
   coef[c] = gamma[c] * invstd[c];
@@ -385,7 +395,7 @@ extern "C" int frx_bn_finalize(int device, frx_stream_t stream, const float* par
   FRX_CHECK_ARG(rows > 0 && C > 0 && count > 0, "bn_finalize: bad sizes");
   FRX_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats come together");
   FRX_ENTER(device);
-  hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, partial, rows, C,
+  hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, partial, rows, C,
                      (double)count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
   FRX_LAUNCH_CHECK();
   return FRX_OK;
@@ -423,7 +433,7 @@ extern "C" int frx_block_merge_fwd(int device, frx_stream_t stream, int dtype, i
 
 extern "C" int frx_bn_bwd_partial_rows(int64_t rows, int C) {
   long b = (rows + 31) / 32;
-  if (b > 1024) b = 1024;
+  if (b > 512) b = 512;
   if (b < 1) b = 1;
   (void)C;
   return (int)b;
@@ -457,7 +467,7 @@ extern "C" int frx_bn_bwd_finalize(int device, frx_stream_t stream, const float*
                                    float* dbeta, float* coef) {
   FRX_CHECK_ARG(partial && gamma && invstd && coef && nblk > 0 && C > 0 && count > 0, "bn_bwd_finalize: bad args");
   FRX_ENTER(device);
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, partial, nblk, C,
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, partial, nblk, C,
                      (double)count, gamma, invstd, dgamma, dbeta, coef);
   FRX_LAUNCH_CHECK();
   return FRX_OK;

@@ -138,12 +138,16 @@ extern "C" int frx_conv_wgrad(int device, frx_stream_t stream, const frx_conv_de
   a.tilesCi = cdiv(ci_extent, bt);
   const int nchunks = cdiv(a.M, kp);
   const int tiles = a.tilesCo * a.tilesCi * taps;
-  int splits = cdiv(1024, tiles);
-  if (splits > cdiv(nchunks, 8)) splits = cdiv(nchunks, 8);
+  // Split the pixel axis so ~3 blocks per CU exist, but keep >= 16 K-chunks per block (below that
+  // the 64-atomics-per-lane epilogue dominates); round to a multiple of 8 for the XCD mapping.
+  int splits = cdiv(768, tiles);
+  if (splits > nchunks / 16) splits = nchunks / 16;
+  if (splits >= 8) splits = splits / 8 * 8;
   if (splits < 1) splits = 1;
   a.chunks_per_split = cdiv(nchunks, splits);
   splits = cdiv(nchunks, a.chunks_per_split);
-  dim3 grid(a.tilesCo * a.tilesCi, taps, splits), block(256);
+  a.splits = splits;
+  dim3 grid(a.tilesCo * a.tilesCi * taps * splits), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (d->dtype == FRX_BF16) {
     if (bt == 64) hipLaunchKernelGGL((k_wgrad<bf16_t, 64>), grid, block, 0, st, a);

@@ -363,7 +363,8 @@ struct WgradArgs {
   int N, Hx, Wx, Ci, Ho, Wo, Co, R, S, stride, pad, M;
   int stem;
   int tilesCo, tilesCi;
-  int chunks_per_split;   // K-chunks (of KP pixels) per blockIdx.z
+  int chunks_per_split;   // K-chunks (of KP pixels) per split
+  int splits;
 };
 
 // XOR swizzle of the 32-byte slot inside a pixel row so the 8 pixel rows a half-wave touches
@@ -384,13 +385,17 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
   static_assert(LD >= 1, "tile too small");
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KP * RB];
 
-  const int tile = blockIdx.x;
+  // 1-D grid, split index fastest: blocks that stream the SAME pixel range (same split, other
+  // tiles / taps) are `splits` apart in dispatch order, i.e. on one XCD when splits % 8 == 0.
+  const int split = blockIdx.x % a.splits;
+  const int rest = blockIdx.x / a.splits;
+  const int tile = rest % (a.tilesCo * a.tilesCi);
+  const int tap = rest / (a.tilesCo * a.tilesCi);
   const int cot = tile / a.tilesCi, cit = tile % a.tilesCi;
-  const int tap = blockIdx.y;
   const int tr_ = tap / a.S, ts_ = tap % a.S;
   const int co0 = cot * BT, ci0 = cit * BT;
   const int nchunks = (a.M + KP - 1) / KP;
-  const int kbeg = blockIdx.z * a.chunks_per_split;
+  const int kbeg = split * a.chunks_per_split;
   const int kend = min(nchunks, kbeg + a.chunks_per_split);
   if (kbeg >= kend) return;
 
@@ -400,6 +405,8 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
   const T* __restrict__ dY = reinterpret_cast<const T*>(a.dY);
   const int hw = a.Ho * a.Wo;
   const int xch = a.stem ? 32 : a.Ci;   // channels (elements) addressable in the X row for this tap-row
+  const bool pointwise = !a.stem && a.R == 1 && a.S == 1 && a.stride == 1;
+  const float inv_hw = 1.0f / (float)hw, inv_wo = 1.0f / (float)a.Wo;
 
   uint4 ry[LD], rx[LD];
   auto load_chunk = [&](int kc) {
@@ -416,16 +423,25 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
       const int ci = ci0 + ch * VEC;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (mok && ci < xch) {
-        const int n = m / hw, rem = m - n * hw;
-        const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
-        if (a.stem) {
-          const long off = (((long)n * a.Hx + oh * 2 + tr_) * a.Wx + ow * 2) * 4 + ci;
-          v = *reinterpret_cast<const uint4*>(X + off);
+        if (pointwise) {                      // 1x1 stride 1: the input pixel IS the output pixel
+          v = *reinterpret_cast<const uint4*>(X + (long)m * a.Ci + ci);
+          if (a.in_scale) v = bn_relu_vec<T>(v, a.in_scale + ci, a.in_shift + ci, a.in_relu);
         } else {
-          const int hi = oh * a.stride - a.pad + tr_, wi = ow * a.stride - a.pad + ts_;
-          if ((unsigned)hi < (unsigned)a.Hx && (unsigned)wi < (unsigned)a.Wx) {
-            v = *reinterpret_cast<const uint4*>(X + (((long)n * a.Hx + hi) * a.Wx + wi) * a.Ci + ci);
-            if (a.in_scale) v = bn_relu_vec<T>(v, a.in_scale + ci, a.in_shift + ci, a.in_relu);
+          int n = (int)((float)m * inv_hw);   // exact after one correction for m < 2^24
+          int rem = m - n * hw;
+          if (rem < 0) { --n; rem += hw; } else if (rem >= hw) { ++n; rem -= hw; }
+          int oh = (int)((float)rem * inv_wo);
+          int ow = rem - oh * a.Wo;
+          if (ow < 0) { --oh; ow += a.Wo; } else if (ow >= a.Wo) { ++oh; ow -= a.Wo; }
+          if (a.stem) {
+            const long off = (((long)n * a.Hx + oh * 2 + tr_) * a.Wx + ow * 2) * 4 + ci;
+            v = *reinterpret_cast<const uint4*>(X + off);
+          } else {
+            const int hi = oh * a.stride - a.pad + tr_, wi = ow * a.stride - a.pad + ts_;
+            if ((unsigned)hi < (unsigned)a.Hx && (unsigned)wi < (unsigned)a.Wx) {
+              v = *reinterpret_cast<const uint4*>(X + (((long)n * a.Hx + hi) * a.Wx + wi) * a.Ci + ci);
+              if (a.in_scale) v = bn_relu_vec<T>(v, a.in_scale + ci, a.in_shift + ci, a.in_relu);
+            }
           }
         }
       }
@@ -511,7 +527,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
   }
 
   const int ldw = a.stem ? 32 : a.Ci;           // elements per (co, r, s-row) line of dW
-  const bool atomic = gridDim.z > 1;
+  const bool atomic = a.splits > 1;
 #pragma unroll
   for (int i = 0; i < F; ++i)
 #pragma unroll
