@@ -390,6 +390,7 @@ __global__ __launch_bounds__(256) void k_head_grad(HeadConst h, const float* __r
                                                    const float* __restrict__ state_t,
                                                    const float* __restrict__ lse,
                                                    const float* __restrict__ gout, float inv_n,
+                                                   const float* __restrict__ dlogits,
                                                    float* __restrict__ gbuf, float* __restrict__ dn) {
   __shared__ float sh[4];
   const int n = blockIdx.x;
@@ -407,7 +408,8 @@ __global__ __launch_bounds__(256) void k_head_grad(HeadConst h, const float* __r
       const float cc = head_clamp<KIND>(craw);
       float z, d, u;
       head_z<KIND>(cc, j == y, h, r, z, d, u);
-      const float g = (expf(z - l) - (j == y ? 1.f : 0.f)) * gs;
+      // upstream gradient: mean-CE in closed form, or an arbitrary dL/dlogits supplied by autograd
+      const float g = dlogits ? dlogits[(long)n * C + j] : (expf(z - l) - (j == y ? 1.f : 0.f)) * gs;
       out = head_pass<KIND>(craw) ? g * d : 0.f;
       if (KIND == FRX_SPHERE) dnorm += g * u;
     }
@@ -619,10 +621,10 @@ extern "C" int frx_head_fwd(int device, frx_stream_t stream, const frx_head_desc
                            norms, loss, lse, topk);
 }
 
-extern "C" int frx_head_bwd(int device, frx_stream_t stream, const frx_head_desc* d, const float* x,
-                            const float* w, const int64_t* labels, const float* state_t,
-                            const float* gout, void* ws, size_t ws_bytes, float* dx, float* dw,
-                            int accumulate_dw) {
+static int head_bwd_impl(int device, frx_stream_t stream, const frx_head_desc* d, const float* x,
+                         const float* w, const int64_t* labels, const float* state_t,
+                         const float* gout, const float* dlogits, void* ws, size_t ws_bytes, float* dx,
+                         float* dw, int accumulate_dw) {
   if (int rc = check_desc(d)) return rc;
   FRX_CHECK_ARG(x && w && labels && ws && dx && dw, "head_bwd: NULL pointer");
   FRX_CHECK_ARG(d->kind != FRX_CURR || state_t, "CurricularFace needs the `t` buffer");
@@ -635,7 +637,7 @@ extern "C" int frx_head_bwd(int device, frx_stream_t stream, const frx_head_desc
 #define FRX_GRAD(K)                                                                                  \
   hipLaunchKernelGGL(k_head_grad<K>, dim3(d->N), dim3(256), 0, st, h, (const float*)W.cbuf, d->C,    \
                      W.Cpad, labels, (const float*)W.xnorm, (const float*)W.ty, state_t,             \
-                     (const float*)W.lse, gout, inv_n, W.gbuf, W.dn)
+                     (const float*)W.lse, gout, inv_n, dlogits, W.gbuf, W.dn)
   switch (d->kind) {
     case FRX_ARC: FRX_GRAD(FRX_ARC); break;
     case FRX_COS: FRX_GRAD(FRX_COS); break;
@@ -686,4 +688,19 @@ extern "C" int frx_head_bwd(int device, frx_stream_t stream, const frx_head_desc
                        (const float*)W.winv, d->D, d->C, dw, accumulate_dw);
   FRX_LAUNCH_CHECK();
   return FRX_OK;
+}
+
+extern "C" int frx_head_bwd(int device, frx_stream_t stream, const frx_head_desc* d, const float* x,
+                            const float* w, const int64_t* labels, const float* state_t,
+                            const float* gout, void* ws, size_t ws_bytes, float* dx, float* dw,
+                            int accumulate_dw) {
+  return head_bwd_impl(device, stream, d, x, w, labels, state_t, gout, nullptr, ws, ws_bytes, dx, dw, accumulate_dw);
+}
+
+extern "C" int frx_head_bwd_dlogits(int device, frx_stream_t stream, const frx_head_desc* d, const float* x,
+                                    const float* w, const int64_t* labels, const float* state_t,
+                                    const float* dlogits, void* ws, size_t ws_bytes, float* dx, float* dw,
+                                    int accumulate_dw) {
+  FRX_CHECK_ARG(dlogits != nullptr, "head_bwd_dlogits: dlogits is NULL");
+  return head_bwd_impl(device, stream, d, x, w, labels, state_t, nullptr, dlogits, ws, ws_bytes, dx, dw, accumulate_dw);
 }

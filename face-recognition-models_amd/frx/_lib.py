@@ -65,6 +65,8 @@ _SIGS = {
     "frx_input_prep": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
     "frx_cast": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int64, _P, _P]),
     "frx_colsum_f32": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, _P, _P]),
+    "frx_head_bwd_dlogits": (C.c_int, [C.c_int, _P, C.POINTER(HeadDesc), _P, _P, _P, _P, _P, _P, C.c_size_t,
+                                       _P, _P, C.c_int]),
     "frx_pair_cosine": (C.c_int, [C.c_int, _P, _P, _P, C.c_int64, C.c_int32, _P]),
     "frx_threshold_count": (C.c_int, [C.c_int, _P, _P, _P, C.c_int64, C.c_float, _P]),
 }

@@ -83,7 +83,9 @@ def resnet50_specs(H=112):
 class ResNet50Engine:
     """Owns parameters, activations and scratch of the backbone; runs forward / backward."""
 
-    def __init__(self, batch, dtype=BF16, device="cuda:0", H=112, extra_params=0):
+    def __init__(self, batch, dtype=BF16, device="cuda:0", H=112, extra_params=0, share=None):
+        """share: another ResNet50Engine (same dtype / device) whose parameters, gradients, momentum,
+        BN buffers and kernel-format weights this plan re-uses -- a plan per batch size, one model."""
         self.N, self.dtype, self.device, self.H = batch, dtype, torch.device(device), H
         self.tdt = ops.TORCH_DT[dtype]
         self.stem, self.blocks, self.h_final = resnet50_specs(H)
@@ -106,9 +108,13 @@ class ResNet50Engine:
         self.extra_off = off
         self.n_params = (off + extra_params + 3) // 4 * 4
         dev = self.device
-        self.params = torch.zeros(self.n_params, device=dev)
-        self.grads = torch.zeros(self.n_params, device=dev)
-        self.mom = torch.zeros(self.n_params, device=dev)
+        if share is not None:
+            assert share.dtype == dtype and share.device == self.device and share.n_params == self.n_params
+            self.params, self.grads, self.mom = share.params, share.grads, share.mom
+        else:
+            self.params = torch.zeros(self.n_params, device=dev)
+            self.grads = torch.zeros(self.n_params, device=dev)
+            self.mom = torch.zeros(self.n_params, device=dev)
         # ---- BN buffers: running stats + batch statistics / affine of the current step
         ctot = sum(c.Co for c in self.convs)
         self.bn_off = {}
@@ -116,21 +122,29 @@ class ResNet50Engine:
         for c in self.convs:
             self.bn_off[c.bn] = o
             o += c.Co
-        self.running_mean = torch.zeros(ctot, device=dev)
-        self.running_var = torch.ones(ctot, device=dev)
-        self.num_batches_tracked = torch.zeros(len(self.convs), dtype=torch.int64, device=dev)
+        if share is not None:
+            self.running_mean, self.running_var = share.running_mean, share.running_var
+            self.num_batches_tracked = share.num_batches_tracked
+        else:
+            self.running_mean = torch.zeros(ctot, device=dev)
+            self.running_var = torch.ones(ctot, device=dev)
+            self.num_batches_tracked = torch.zeros(len(self.convs), dtype=torch.int64, device=dev)
         self.bn_mean = torch.zeros(ctot, device=dev)
         self.bn_invstd = torch.zeros(ctot, device=dev)
         self.bn_scale = torch.zeros(ctot, device=dev)
         self.bn_shift = torch.zeros(ctot, device=dev)
         # ---- kernel-format weights, activations
         N = batch
-        for c in self.convs:
+        for ci_, c in enumerate(self.convs):
             if c.stem:
                 c.desc = ops.conv_desc(dtype, N, H, H, 3, 64, 7, 7, 2, 3, stem=True)
-                c.wk = torch.zeros(64, 7, 8, 4, dtype=self.tdt, device=dev)
             else:
                 c.desc = ops.conv_desc(dtype, N, c.Hi, c.Hi, c.Ci, c.Co, c.k, c.k, c.stride, c.k // 2)
+            if share is not None:
+                c.wk, c.wt = share.convs[ci_].wk, share.convs[ci_].wt
+            elif c.stem:
+                c.wk = torch.zeros(64, 7, 8, 4, dtype=self.tdt, device=dev)
+            else:
                 c.wk = torch.zeros(c.Co, c.k, c.k, c.Ci, dtype=self.tdt, device=dev)
                 c.wt = torch.zeros(c.Ci, c.k, c.k, c.Co, dtype=self.tdt, device=dev)
             c.stat_rows = ops.conv_stat_rows(c.desc)
@@ -145,8 +159,11 @@ class ResNet50Engine:
         self.pooled = torch.empty(N, 2048, dtype=self.tdt, device=dev)
         self.feats = torch.empty(N, FEATURE_DIM, device=dev)
         self.fc_desc = ops.conv_desc(dtype, N, 1, 1, 2048, FEATURE_DIM, 1, 1, 1, 0)
-        self.fc_wk = torch.zeros(FEATURE_DIM, 2048, dtype=self.tdt, device=dev)
-        self.fc_wt = torch.zeros(2048, FEATURE_DIM, dtype=self.tdt, device=dev)
+        if share is not None:
+            self.fc_wk, self.fc_wt = share.fc_wk, share.fc_wt
+        else:
+            self.fc_wk = torch.zeros(FEATURE_DIM, 2048, dtype=self.tdt, device=dev)
+            self.fc_wt = torch.zeros(2048, FEATURE_DIM, dtype=self.tdt, device=dev)
         # ---- scratch
         max_rows = max(c.stat_rows * c.Co for c in self.convs)
         self.stat_partial = torch.empty(2 * max_rows, device=dev)
@@ -159,7 +176,9 @@ class ResNet50Engine:
         self.lr_dev = torch.zeros(1, device=dev)
         self.training = True
         self._eval_affine_ready = False
-        self.reset_parameters()
+        self.share = share
+        if share is None:
+            self.reset_parameters()
 
     # ------------------------------------------------------------------ parameter views
     def w_master(self, c: ConvSpec):
@@ -225,7 +244,8 @@ class ResNet50Engine:
             else:
                 ops.weight_prep(self.dtype, c.Co, c.k * c.k, c.Ci, self.w_master(c), krsc=c.wk, crsk=c.wt)
         ops.weight_prep(self.dtype, FEATURE_DIM, 1, 2048, self.fc_w(), krsc=self.fc_wk, crsk=self.fc_wt)
-        self._eval_affine_ready = False
+        owner = self.share or self
+        owner.weights_version = getattr(owner, "weights_version", 0) + 1
 
     # ------------------------------------------------------------------ forward
     def _conv_bn(self, c: ConvSpec, x, prev: ConvSpec | None):
@@ -248,17 +268,25 @@ class ResNet50Engine:
         for c in self.convs:
             ops.bn_eval_affine(self.gamma(c), self.beta(c), self._bn(self.running_mean, c),
                                self._bn(self.running_var, c), self._bn(self.bn_scale, c), self._bn(self.bn_shift, c), BN_EPS)
-        self._eval_affine_ready = True
 
     def forward(self, images):
         """images: fp32 NCHW in [-1,1] or uint8 NHWC; returns feats [N,512] fp32 (engine-owned)."""
         N, dt = self.N, self.dtype
         if images.shape[0] != N:
             raise ops.FrxError(f"engine was planned for batch {N}, got {images.shape[0]}")
-        if not self.training and not self._eval_affine_ready:
-            self._prepare_eval_affine()
+        if not self.training:
+            # batch statistics of a training step overwrite scale/shift, and running statistics move:
+            # rebuild the eval affine whenever weights or statistics changed since it was made
+            owner = self.share or self
+            stamp = (getattr(owner, "weights_version", 0), int(getattr(owner, "stats_version", 0)))
+            if self._eval_affine_ready != stamp:
+                self._prepare_eval_affine()
+                self._eval_affine_ready = stamp
         if self.training:
             self.num_batches_tracked += 1
+            owner = self.share or self
+            owner.stats_version = getattr(owner, "stats_version", 0) + 1
+            self._eval_affine_ready = False
         ops.input_prep(dt, images, self.xin)
         s = self.stem
         self._conv_bn(s, self.xin, None)
@@ -432,23 +460,27 @@ HEAD_DEFAULTS = {ops.ARC: (64.0, 0.5), ops.COS: (64.0, 0.35), ops.SPHERE: (1.0, 
 class FaceEngine:
     """Backbone + margin head + fused SGD: one training step = forward, CE, backward, update."""
 
-    def __init__(self, kind, num_classes, batch, dtype=BF16, device="cuda:0", s=None, m=None, momentum=0.01, seed=None):
+    def __init__(self, kind, num_classes, batch, dtype=BF16, device="cuda:0", s=None, m=None, momentum=0.01, seed=None,
+                 share=None):
         self.kind = HEAD_KINDS[kind] if isinstance(kind, str) else kind
         self.C, self.N = num_classes, batch
         ds, dm = HEAD_DEFAULTS[self.kind]
         self.s, self.m = (ds if s is None else s), (dm if m is None else m)
         self.w_cd = self.kind in (ops.ARC, ops.SPHERE)
-        self.net = ResNet50Engine(batch, dtype, device, extra_params=num_classes * FEATURE_DIM)
+        self.net = ResNet50Engine(batch, dtype, device, extra_params=num_classes * FEATURE_DIM,
+                                  share=None if share is None else share.net)
         self.device = self.net.device
         self.head = ops.HeadContext(self.kind, batch, FEATURE_DIM, num_classes, self.s, self.m, momentum, device=self.device)
-        self.t = torch.zeros(1, device=self.device)          # CurricularFace buffer `t` (criterion.py:517)
+        # CurricularFace buffer `t` (criterion.py:517)
+        self.t = torch.zeros(1, device=self.device) if share is None else share.t
         self.sphere_iter = 0                                 # SphereFace.iter (criterion.py:33): python int
         self.dfeat = torch.empty(batch, FEATURE_DIM, device=self.device)
         self.last = None
         self.world = 1
         self.allreduce = None                                # callable(flat fp32 grads) for data parallel
         self.ty_allreduce = None
-        self.reset_head(seed)
+        if share is None:
+            self.reset_head(seed)
 
     # head weight views, in the reference's own layouts (SURVEY H7)
     def head_w(self, buf=None):

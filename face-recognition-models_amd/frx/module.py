@@ -1,0 +1,252 @@
+"""nn.Module facade over the native engine, so the reference's object model keeps working:
+
+    model = ArcFaceNet(num_classes, backbone).to(device); model.train() / .eval()
+    (cos_s, logits), norms, loss_g, one_hot = model(images, labels)     # training
+    feats = model(images)                                               # eval
+    model.state_dict() / load_state_dict() with the reference's key names
+    torch.optim.SGD(model.parameters(), ...)                            # a foreign optimiser still works
+
+Parameters are registered as ordinary nn.Parameters (torchvision / reference names and shapes).
+They start on the CPU; the first forward on a HIP device builds the engine, copies them in and then
+RE-POINTS each Parameter at its slice of the engine's flat fp32 buffer (conv weights as
+channels-last-strided views of the KRSC master copy), so optimiser updates land directly in engine
+memory.  A version check re-derives the bf16 kernel-format weights when something else modified them.
+
+There is no CPU execution path: forward on a CPU tensor raises FrxError.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from . import engine as E
+from . import ops
+from ._lib import FrxError
+
+_DTYPES = {"bf16": ops.BF16, "f32": ops.F32, "fp32": ops.F32, "float32": ops.F32, "bfloat16": ops.BF16}
+
+
+class NativeBackbone(nn.Module):
+    """ResNet-50 parameter container with torchvision's state-dict layout (backbones.py:16-18 upstream:
+    torchvision resnet50 + nn.Linear(2048, FEATURE_DIM)).  Holds no arithmetic of its own."""
+
+    def __init__(self, feature_dim=E.FEATURE_DIM):
+        super().__init__()
+        if feature_dim != E.FEATURE_DIM:
+            raise ValueError(f"native backbone emits {E.FEATURE_DIM}-d features")
+        stem, blocks, _ = E.resnet50_specs()
+        self._specs = [stem] + [c for b in blocks for c in (b.conv1, b.conv2, b.conv3, b.down) if c is not None]
+        g = torch.Generator().manual_seed(torch.initial_seed() % (2 ** 31))
+        for c in self._specs:
+            k = 7 if c.stem else c.k
+            w = torch.randn(c.Co, c.Ci, k, k, generator=g) * math.sqrt(2.0 / (c.Co * k * k))   # kaiming fan_out
+            self._reg(c.name + ".weight", nn.Parameter(w))
+            self._reg(c.bn + ".weight", nn.Parameter(torch.ones(c.Co)))
+            self._reg(c.bn + ".bias", nn.Parameter(torch.zeros(c.Co)))
+            self._reg(c.bn + ".running_mean", torch.zeros(c.Co), buffer=True)
+            self._reg(c.bn + ".running_var", torch.ones(c.Co), buffer=True)
+            self._reg(c.bn + ".num_batches_tracked", torch.zeros((), dtype=torch.long), buffer=True)
+        bound = 1.0 / math.sqrt(2048)
+        self._reg("fc.weight", nn.Parameter((torch.rand(feature_dim, 2048, generator=g) * 2 - 1) * bound))
+        self._reg("fc.bias", nn.Parameter((torch.rand(feature_dim, generator=g) * 2 - 1) * bound))
+
+    def _reg(self, dotted, tensor, buffer=False):
+        """register under nested sub-modules so state_dict keys read 'layer1.0.conv1.weight'"""
+        mod = self
+        *path, leaf = dotted.split(".")
+        for p in path:
+            if not hasattr(mod, p):
+                mod.add_module(p, nn.Module())
+            mod = getattr(mod, p)
+        if buffer:
+            mod.register_buffer(leaf, tensor)
+        else:
+            mod.register_parameter(leaf, tensor)
+
+    def forward(self, x):
+        raise FrxError("NativeBackbone is driven through its owning *Net module (no standalone forward)")
+
+
+class NativeFaceNet(nn.Module):
+    """Base of ArcFaceNet / CosFaceNet / SphereFaceNet / CurricularFaceNet."""
+
+    head_attr = "head"          # attribute name of the head module == state-dict prefix
+    kind = ops.ARC
+
+    def __init__(self, head_module, backbone_module, compute_dtype="bf16"):
+        super().__init__()
+        self.backbone = backbone_module
+        setattr(self, self.head_attr, head_module)
+        self._dtype = _DTYPES[compute_dtype]
+        self._engines = {}            # batch size -> FaceEngine (all sharing the first one's parameters)
+        self._primary = None
+        self._synced_version = None
+        self._last_ctx = None
+
+    # ------------------------------------------------------------------ engine management
+    @property
+    def head(self):
+        return getattr(self, self.head_attr)
+
+    def _head_param(self):
+        return self.head.weight if hasattr(self.head, "weight") else self.head.kernel
+
+    def _engine_for(self, n, device):
+        if device.type != "cuda":
+            raise FrxError("the native face-recognition path runs on a HIP device only: move the model and the "
+                           "batch with .to('cuda') (there is no CPU fallback)")
+        if self._primary is not None and self._primary.device != device:
+            raise FrxError(f"model engine lives on {self._primary.device}, batch is on {device}")
+        eng = self._engines.get(n)
+        if eng is not None:
+            return eng
+        h = self.head
+        eng = E.FaceEngine(self.kind, h.num_classes, n, dtype=self._dtype, device=device, s=h.s, m=float(h.m),
+                           momentum=getattr(h, "momentum", 0.01), share=self._primary)
+        if self._primary is None:
+            self._adopt(eng)
+        self._engines[n] = eng
+        return eng
+
+    def _adopt(self, eng):
+        """first engine: load the module's current tensors, then alias every Parameter / buffer to it"""
+        net = eng.net
+        sd = {k: v.detach() for k, v in self.backbone.state_dict().items()}
+        net.load_state_dict(sd)
+        eng.head_w().copy_(self._head_param().detach().to(eng.device))
+        if hasattr(self.head, "t"):
+            eng.t.copy_(self.head.t.detach().to(eng.device))
+        mods = dict(self.backbone.named_modules())
+
+        def sub(dotted):
+            path, leaf = dotted.rsplit(".", 1)
+            return mods[path], leaf
+        for i, c in enumerate(net.convs):
+            w = net.w_master(c)
+            g = net.w_grad(c)
+            if c.stem:
+                w, g = w[:, :, :7, :3], g[:, :, :7, :3]
+            m, leaf = sub(c.name + ".weight")
+            self._alias(m, leaf, w.permute(0, 3, 1, 2), g.permute(0, 3, 1, 2))
+            m, _ = sub(c.bn + ".weight")
+            self._alias(m, "weight", net.gamma(c), net.gamma(c, net.grads))
+            self._alias(m, "bias", net.beta(c), net.beta(c, net.grads))
+            m.running_mean = net._bn(net.running_mean, c)
+            m.running_var = net._bn(net.running_var, c)
+            m.num_batches_tracked = net.num_batches_tracked[i]
+        self._alias(self.backbone.fc, "weight", net.fc_w(), net.fc_w(net.grads))
+        self._alias(self.backbone.fc, "bias", net.fc_b(), net.fc_b(net.grads))
+        pname = "weight" if hasattr(self.head, "weight") else "kernel"
+        self._alias(self.head, pname, eng.head_w(), eng.head_w(net.grads))
+        if hasattr(self.head, "t"):
+            self.head.t = eng.t
+        self._primary = eng
+        self._param_list = list(self.parameters())
+        self._synced_version = self._version_sum()
+
+    def _alias(self, module, leaf, view, grad_view):
+        p = getattr(module, leaf)
+        p.data = view                     # same storage as the engine's flat buffer from now on
+        p._frx_grad = grad_view
+
+    def _version_sum(self):
+        # a Parameter re-pointed with `.data = view` keeps its OWN version counter, bumped by every
+        # in-place write through it (torch optimiser step, load_state_dict's copy_)
+        return sum(p._version for p in self._param_list)
+
+    def _resync_if_touched(self):
+        """Parameters were modified in place through the nn.Parameter aliases: re-derive the
+        kernel-format (bf16 KRSC / CRSK) copies before they are used."""
+        v = self._version_sum()
+        if v != self._synced_version:
+            self._primary.net.sync_weights()
+            self._synced_version = v
+
+    # ------------------------------------------------------------------ nn.Module surface
+    def _apply(self, fn, *a, **k):
+        if self._primary is not None:
+            probe = torch.empty(0, device=self._primary.device)
+            moved = fn(probe)
+            if moved.device == probe.device and moved.dtype == probe.dtype:
+                return self                   # .to(same device) / .float(): nothing to do
+            raise FrxError("the model is bound to its HIP engine; move it with .to(device) BEFORE the first forward")
+        return super()._apply(fn, *a, **k)
+
+    def state_dict(self, *args, **kwargs):
+        """reference key names; tensors are contiguous copies (the live parameters are strided views
+        into the engine's flat buffer)"""
+        sd = super().state_dict(*args, **kwargs)
+        if kwargs.get("keep_vars", False):
+            return sd
+        for k in list(sd.keys()):
+            sd[k] = sd[k].detach().clone().contiguous()
+        return sd
+
+    def forward(self, x, labels=None):
+        eng = self._engine_for(x.shape[0], x.device)
+        self._resync_if_touched()
+        if not self.training:
+            with torch.no_grad():
+                eng.net.training = False
+                return eng.net.forward(x.contiguous()).clone()          # raw feats [N,512], like the reference
+        assert labels is not None
+        return _TrainForward.run(self, eng, x, labels)
+
+    # grads: autograd's zero_grad(set_to_none=True) drops .grad; the engine's flat gradient buffer is the
+    # real accumulator, so "all grads are None" means "logically zero" and is applied before accumulating
+    def _begin_backward(self):
+        eng = self._primary
+        params = list(self.parameters())
+        if all(p.grad is None for p in params):
+            eng.net.grads.zero_()
+        return params
+
+    def _publish_grads(self, params):
+        for p in params:
+            if p.grad is None:
+                p.grad = p._frx_grad
+
+
+class _TrainForward(torch.autograd.Function):
+    """logits = F(images): forward runs backbone + head on the engine; backward receives dL/dlogits from
+    whatever criterion the caller applied (model_utils.py:178-185) and replays the native backward."""
+
+    @staticmethod
+    def run(model, eng, x, labels):
+        labels = labels.contiguous()
+        h = model.head
+        eng.net.training = True
+        with torch.no_grad():
+            lamb = 0.0
+            if eng.kind == ops.SPHERE:               # SphereFace.iter lives on the module (criterion.py:33,58-60)
+                h.iter += 1
+                h.lamb = max(h.LambdaMin, h.base * (1 + h.gamma * h.iter) ** (-h.power))
+                lamb = h.lamb
+            feats = eng.net.forward(x.contiguous())
+            out = ops.head_forward(eng.head, feats, eng.head_w(), labels, state_t=eng.t, lamb=lamb, want_logits=True,
+                                   ty_allreduce=eng.ty_allreduce)
+        anchor = model._head_param()
+        logits = _TrainForward.apply(anchor, out["logits"], model, eng, labels)
+        one_hot = torch.zeros_like(out["cos_s"]).scatter_(1, labels.view(-1, 1), 1.0)
+        model._last_ctx = out
+        return [out["cos_s"], logits], out["norms"].view(-1, 1), 0, one_hot
+
+    @staticmethod
+    def forward(ctx, anchor, logits, model, eng, labels):
+        ctx.model, ctx.eng, ctx.labels = model, eng, labels
+        return logits.view_as(logits)
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        model, eng, labels = ctx.model, ctx.eng, ctx.labels
+        params = model._begin_backward()
+        ops.head_backward_dlogits(eng.head, eng.net.feats, eng.head_w(), labels, dlogits.contiguous().float(),
+                                  state_t=eng.t, dx=eng.dfeat, dw=eng.head_w(eng.net.grads), accumulate_dw=True)
+        eng.net.backward(eng.dfeat)
+        if eng.allreduce is not None:
+            eng.allreduce(eng.net.grads)
+            eng.net.grads.mul_(1.0 / eng.world)
+        model._publish_grads(params)
+        return None, None, None, None, None

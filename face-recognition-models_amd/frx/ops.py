@@ -123,6 +123,20 @@ def head_backward(ctx: HeadContext, x, w, labels, state_t=None, gout=None, dx=No
     return dx, dw
 
 
+def head_backward_dlogits(ctx: HeadContext, x, w, labels, dlogits, state_t=None, dx=None, dw=None, accumulate_dw=False):
+    """Backward for an arbitrary dL/dlogits [N,C] (autograd-compatible path)."""
+    N, D, Cc = ctx.shape
+    _chk(dlogits, torch.float32, "dlogits")
+    if tuple(dlogits.shape) != (N, Cc):
+        raise FrxError(f"dlogits shape {tuple(dlogits.shape)} != ({N}, {Cc})")
+    dx = torch.empty_like(x) if dx is None else dx
+    dw = torch.empty_like(w) if dw is None else dw
+    check(_lib.lib().frx_head_bwd_dlogits(_dev(x), _stream(x), C.byref(ctx.desc), _p(x), _p(w), _p(labels),
+                                          _p(state_t), _p(dlogits), _p(ctx.ws), ctx.nbytes, _p(dx), _p(dw),
+                                          int(bool(accumulate_dw))), "frx_head_bwd_dlogits")
+    return dx, dw
+
+
 def pair_cosine(f1, f2):
     _chk(f1, torch.float32, "f1"); _chk(f2, torch.float32, "f2")
     if f1.shape != f2.shape or f1.dim() != 2:

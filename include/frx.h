@@ -94,6 +94,12 @@ int frx_head_bwd(int device, frx_stream_t stream, const frx_head_desc* d, const 
                  const float* w, const int64_t* labels, const float* state_t, const float* gout,
                  void* ws, size_t ws_bytes, float* dx, float* dw, int accumulate_dw);
 
+/* Same, for an ARBITRARY upstream gradient dlogits [N,C] = dL/dlogits (what autograd hands back when
+ * a caller applies its own criterion to the returned logits, model_utils.py:178-185). */
+int frx_head_bwd_dlogits(int device, frx_stream_t stream, const frx_head_desc* d, const float* x,
+                         const float* w, const int64_t* labels, const float* state_t, const float* dlogits,
+                         void* ws, size_t ws_bytes, float* dx, float* dw, int accumulate_dw);
+
 /* ---------------------------------------------------------------- verification
  * Replaces F.normalize(feat1) * F.normalize(feat2) .sum(1) and the threshold count of
  * evaluate()/tune_threshold_roc() (model_utils.py:370-375, 391-393). */

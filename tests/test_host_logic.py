@@ -1,0 +1,231 @@
+"""CPU: host-side logic of the drop-in layer (utils/*, frx/verify.py, frx/ddp.py) against the golden
+vectors captured from the reference (loop ordering, loss averaging, LR schedule, verification arithmetic,
+checkpoint rotation) and a world-size-2 gloo rehearsal of the data-parallel gradient exchange."""
+import os
+import sys
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle.resnet50 import TorchHead
+from oracle import heads as H
+
+
+def test_config_names_and_values():
+    from utils import config as c
+    assert c.FEATURE_DIM == 512 and c.LAMBDA_G == 0.0
+    assert (c.M_arc, c.S_arc) == (0.5, 64.0) and (c.M_cos, c.S_cos) == (0.35, 64.0)
+    assert c.M_sphere == 2 and (c.M_curricular, c.S_curricular, c.MOMENTUM_curricular) == (0.5, 64.0, 0.01)
+    assert isinstance(c.DATASET_PATH, str) and isinstance(c.WORKING_PATH, str) and isinstance(c.BACKBONE, str)
+
+
+def test_accuracy_and_scheduler_match_reference(golden_dir):
+    from utils.metrics import accuracy
+    from utils.schedulers import get_scheduler
+    g = np.load(os.path.join(golden_dir, "heads_cosface.npz"))
+    a1, a5 = accuracy(torch.from_numpy(g["warm_cos_s"]), torch.from_numpy(g["warm_y"]), topk=(1, 5))
+    assert a1.shape == (1,) and a1.item() == pytest.approx(float(g["warm_acc1"]), abs=1e-4)
+    assert a5.item() == pytest.approx(float(g["warm_acc5"]), abs=1e-4)
+    lin = nn.Linear(2, 2)
+    opt = torch.optim.SGD(lin.parameters(), lr=0.1, momentum=0.9, weight_decay=5e-4)
+    sch = get_scheduler(opt, "customstep")
+    lrs = []
+    for _ in range(70):
+        lrs.append(opt.param_groups[0]["lr"])
+        opt.step()
+        sch.step()
+    np.testing.assert_allclose(lrs, np.load(os.path.join(golden_dir, "customstep_lr.npz"))["lrs"], rtol=1e-12)
+    sd = sch.state_dict()                       # survives a weights_only checkpoint round trip
+    sch2 = get_scheduler(opt, "customstep")
+    sch2.load_state_dict(sd)
+    assert sch2.steps == sch.steps and sch2.last_epoch == sch.last_epoch
+    with pytest.raises(ValueError):
+        get_scheduler(opt, "no-such-schedule")
+
+
+class _Toy(nn.Module):
+    """same toy as tests/golden/make_golden.py, with the oracle's autograd ArcFace head"""
+
+    def __init__(self, init):
+        super().__init__()
+        self.backbone = nn.Sequential(nn.Flatten(), nn.Linear(3 * 8 * 8, 64))
+        self.arcface = TorchHead(H.ARC, 64, 10, H.HeadHyper.default(H.ARC))
+        with torch.no_grad():
+            self.backbone[1].weight.copy_(torch.from_numpy(init["init.backbone.1.weight"]))
+            self.backbone[1].bias.copy_(torch.from_numpy(init["init.backbone.1.bias"]))
+            self.arcface.weight.copy_(torch.from_numpy(init["init.arcface.weight"]))
+
+    def forward(self, x, labels=None):
+        f = self.backbone(x)
+        if not self.training:
+            return f
+        cos_s, logits = self.arcface(f, labels)
+        return [cos_s, logits], torch.norm(f, dim=1, keepdim=True), 0, None
+
+
+def test_train_model_loop_matches_reference(golden_dir, monkeypatch):
+    """train_model on a foreign (CPU, pure-torch) model: step ordering, loss averaging weights, skipped
+    empty batches, per-step logging -- against the log captured from the reference's train_model."""
+    from utils import model_utils as MU
+    g = np.load(os.path.join(golden_dir, "train_loop_toy.npz"))
+    logs = []
+    monkeypatch.setattr(MU.wandb, "log", lambda d, step=None: logs.append(dict(d)), raising=False)
+    net = _Toy(g)
+    batches = [(torch.from_numpy(g["images"][i]), torch.from_numpy(g["labels"][i])) for i in range(3)]
+    batches.insert(1, (None, None))
+    opt = torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9, weight_decay=5e-4)
+    args = types.SimpleNamespace(lambda_g=0.0, print_freq=1000)
+    MU._ITERS["n"] = -1
+    avg = MU.train_model(net, batches, nn.CrossEntropyLoss(), opt, MU.GradScaler(enabled=False), torch.device("cpu"), 1, 1, args)
+    assert avg == pytest.approx(float(g["avg_loss"]), rel=1e-5)
+    for key in ["loss", "loss_id", "acc1", "acc5", "lr", "epoch", "step"]:
+        np.testing.assert_allclose([d[key] for d in logs], g["log_" + key], rtol=2e-5, atol=1e-5, err_msg=key)
+    np.testing.assert_allclose(net.backbone[1].weight.detach().numpy(), g["final.backbone.1.weight"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(net.arcface.weight.detach().numpy(), g["final.arcface.weight"], rtol=1e-4, atol=1e-5)
+
+
+def test_verify_arithmetic_matches_reference(golden_dir):
+    from frx import verify as V
+    thr = np.load(os.path.join(golden_dir, "verify_threshold.npz"))
+    for tag in "abc":
+        fpr, tpr, ths = V.roc_points(thr[f"{tag}_same"], thr[f"{tag}_cos"])
+        np.testing.assert_array_equal(fpr, thr[f"{tag}_fpr"])
+        np.testing.assert_array_equal(tpr, thr[f"{tag}_tpr"])
+        np.testing.assert_array_equal(ths, thr[f"{tag}_thrs"])
+        assert V.youden_threshold(thr[f"{tag}_same"], thr[f"{tag}_cos"]) == float(thr[f"{tag}_thr"])
+        assert V.auc(thr[f"{tag}_same"], thr[f"{tag}_cos"]) == pytest.approx(float(thr[f"{tag}_auc"]), abs=1e-12)
+    kf = np.load(os.path.join(golden_dir, "verify_kfold_sets.npz"))
+    for tag in ("lfw", "rag", "zf"):
+        np.testing.assert_array_equal(V.stratified_folds(kf[f"{tag}_labels"].astype(np.int64)), kf[f"{tag}_folds"])
+
+
+def test_kfold_protocol_and_reference_entry_points(golden_dir):
+    """evaluate / tune_threshold_roc / compute_auc with a foreign CPU model and the shipped 10-fold protocol
+    on cached similarities, against the numbers the reference produced."""
+    from torch.utils.data import TensorDataset
+    from utils import model_utils as MU
+    thr = np.load(os.path.join(golden_dir, "verify_threshold.npz"))
+    ident = nn.Identity()
+    for tag in "abc":
+        ds = TensorDataset(torch.from_numpy(thr[f"{tag}_f1"]), torch.from_numpy(thr[f"{tag}_f2"]), torch.from_numpy(thr[f"{tag}_same"]))
+        t, acc = MU.tune_threshold_roc(ident, ds, 64, torch.device("cpu"))
+        assert t == pytest.approx(float(thr[f"{tag}_thr"]), abs=2e-6) and acc == pytest.approx(float(thr[f"{tag}_acc"]), abs=0.2)
+        assert MU.evaluate(ident, ds, 64, torch.device("cpu"), 0.33) == pytest.approx(float(thr[f"{tag}_eval_acc"][1]), abs=1e-9)
+        assert MU.compute_auc(ident, ds, 64, torch.device("cpu")) == pytest.approx(float(thr[f"{tag}_auc"]), abs=1e-5)
+    e2e = np.load(os.path.join(golden_dir, "verify_kfold_e2e.npz"))
+    f1, f2 = torch.from_numpy(e2e["f1"]), torch.from_numpy(e2e["f2"])
+    cos = (torch.nn.functional.normalize(f1, dim=1) * torch.nn.functional.normalize(f2, dim=1)).sum(1)
+    res = MU.kfold_from_similarities(cos, e2e["same"], 10)
+    ref = e2e["result"]
+    assert res[0] == pytest.approx(ref[0], abs=0.2)          # the north-star +-0.2 % bar
+    assert res[0] == pytest.approx(ref[0], abs=0.02) and res[1] == pytest.approx(ref[1], abs=0.05)
+    assert res[2] == pytest.approx(ref[2], abs=1e-6) and res[3] == pytest.approx(ref[3], abs=1e-6)
+
+
+def test_pair_list_parser(tmp_path):
+    from utils.model_utils import read_pair_list
+    p = tmp_path / "pair.list"
+    p.write_text("1 2 1\n\n3   4\t0\nbad line\n5 6 1 extra\n")
+    np.testing.assert_array_equal(read_pair_list(str(p)), [[1, 2, 1], [3, 4, 0], [5, 6, 1]])
+    (tmp_path / "empty.list").write_text("")
+    assert read_pair_list(str(tmp_path / "empty.list")).shape == (0, 3)
+
+
+def test_checkpoint_rotation_and_resume(tmp_path):
+    from utils import model_utils as MU
+    from utils.schedulers import get_scheduler
+    net = nn.Linear(4, 3)
+    opt = torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9)
+    sch = get_scheduler(opt, "customstep")
+    d = str(tmp_path / "ck")
+    assert MU.load_latest_checkpoint(net, opt, sch, None, d, "M", "cpu") == (1, None)
+    for e in range(1, 6):
+        MU.save_checkpoint(net, opt, sch, None, 1.0 / e, e, d, "M", isCheckpoint=True)
+    assert sorted(os.listdir(d)) == [f"M_checkpoint_epoch_{e}.pth" for e in (3, 4, 5)]
+    MU.save_checkpoint(net, opt, sch, None, 0.123, 4, d, "M", isCheckpoint=False)
+    w = net.weight.detach().clone()
+    with torch.no_grad():
+        net.weight.zero_()
+    assert MU.load_latest_checkpoint(net, opt, sch, None, d, "M", "cpu", isCheckpoint=True) == (6, pytest.approx(0.2))
+    assert torch.equal(net.weight, w)
+    assert MU.load_latest_checkpoint(net, None, None, None, d, "M", "cpu", isCheckpoint=False) == (5, pytest.approx(0.123))
+    assert os.listdir(d) == ["M_min_loss.pth"]          # min-loss resume drops the epoch checkpoints, like upstream
+
+
+def test_parse_args_defaults():
+    from utils.model_utils import parse_args
+    a = parse_args([])
+    assert (a.batch_size, a.epochs, a.learning_rate, a.lambda_g, a.print_freq, a.continue_train) == (512, 30, 0.1, 0.0, 100, None)
+    a = parse_args(["-bs", "256", "-e", "2", "-lr", "0.01", "--continue_train", "latest"])
+    assert (a.batch_size, a.epochs, a.learning_rate, a.continue_train) == (256, 2, 0.01, "latest")
+
+
+def test_model_classes_keep_reference_contract():
+    from utils.backbones import get_backbone
+    from utils.criterion import ArcFace, ArcFaceNet, CosFaceNet, CurricularFaceNet, SphereFaceNet
+    from frx import FrxError
+    m = ArcFaceNet(num_classes=37, backbone="resnet50")
+    keys = list(m.state_dict())
+    assert keys[0] == "backbone.conv1.weight" and "backbone.layer4.2.bn3.num_batches_tracked" in keys
+    assert m.state_dict()["arcface.weight"].shape == (37, 512) and m.loss_model == "arcface"
+    assert CosFaceNet(5, "resnet50").state_dict()["cosface.kernel"].shape == (512, 5)
+    assert SphereFaceNet(5, "resnet50").state_dict()["sphereface.weight"].shape == (5, 512)
+    cur = CurricularFaceNet(5, "resnet50").state_dict()
+    assert cur["curricular.kernel"].shape == (512, 5) and cur["curricular.t"].shape == (1,)
+    with pytest.raises(ValueError):
+        get_backbone("vgg16")
+    with pytest.raises(NotImplementedError):
+        get_backbone("resnet18")
+    with pytest.raises(NotImplementedError):
+        ArcFace(512, 10, easy_margin=True)
+    with pytest.raises(FrxError):                      # fails loudly off-GPU: no CPU fallback
+        m(torch.zeros(2, 3, 112, 112), torch.zeros(2, dtype=torch.long))
+    sd = {k: v.clone() for k, v in m.state_dict().items()}
+    sd["backbone.fc.bias"] += 1
+    m.load_state_dict(sd)
+    assert torch.equal(m.backbone.fc.bias.detach(), sd["backbone.fc.bias"])
+
+
+def test_bucket_ranges():
+    from frx.ddp import bucket_ranges
+    r = bucket_ranges(29976448, 4)
+    assert r[0][1] == 29976448 and r[-1][0] == 0
+    assert sorted(lo for lo, _ in r) == sorted(set(lo for lo, _ in r))
+    covered = sorted(r)
+    assert all(a[1] == b[0] for a, b in zip(covered, covered[1:])) and all(lo % 256 == 0 for lo, _ in r)
+    assert bucket_ranges(10, 4) == [(0, 10)]
+
+
+def _ddp_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from frx import ddp
+    flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)
+    ddp.GradAllReducer(None, n_buckets=3, via_host=False)(flat)           # CPU tensors: gloo reduces them directly
+    flat2 = torch.full((7,), float(rank + 1))
+    ddp.GradAllReducer(None, n_buckets=2, via_host=True)(flat2)
+    ty = torch.tensor([float(rank + 2)])
+    cnt = ddp.TargetCosineAllReducer(16, None, via_host=True)(ty)
+    out.put((rank, flat.sum().item(), flat2.tolist(), ty.item(), cnt))
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world2_gloo():
+    """N>1 rehearsal on the CPU: bucketed SUM all-reduce and the CurricularFace target-cosine exchange."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(60)
+    expect = float(torch.arange(1000, dtype=torch.float32).sum() * 3)
+    for rank, s, f2, ty, cnt in res:
+        assert s == pytest.approx(expect) and f2 == [3.0] * 7 and ty == 5.0 and cnt == 32
