@@ -22,9 +22,20 @@ static int launch_igemm(hipStream_t st, ConvArgs a) {
   a.tilesM = cdiv(a.M, c.bm);
   a.tilesN = cdiv(a.Ncol, c.bn);
   const int grid = (int)round_up(a.tilesM, 8) * a.tilesN;
-  if (c.bm == 128 && c.bn == 128) hipLaunchKernelGGL((k_igemm<T, 128, 128, 2, 2>), dim3(grid), dim3(256), 0, st, a);
-  else if (c.bm == 128 && c.bn == 64) hipLaunchKernelGGL((k_igemm<T, 128, 64, 2, 2>), dim3(grid), dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((k_igemm<T, 64, 64, 2, 2>), dim3(grid), dim3(256), 0, st, a);
+#define FRX_IGEMM(BM_, BN_, MODE_, PRO_) \
+  hipLaunchKernelGGL((k_igemm<T, BM_, BN_, 2, 2, MODE_, PRO_>), dim3(grid), dim3(256), 0, st, a)
+#define FRX_IGEMM_TILE(MODE_, PRO_)                                   \
+  do {                                                                \
+    if (c.bm == 128 && c.bn == 128) FRX_IGEMM(128, 128, MODE_, PRO_); \
+    else if (c.bm == 128 && c.bn == 64) FRX_IGEMM(128, 64, MODE_, PRO_); \
+    else FRX_IGEMM(64, 64, MODE_, PRO_);                              \
+  } while (0)
+  if (a.mode == MODE_STEM) FRX_IGEMM_TILE(MODE_STEM, false);
+  else if (a.mode == MODE_DGRAD) FRX_IGEMM_TILE(MODE_DGRAD, false);
+  else if (a.in_scale) FRX_IGEMM_TILE(MODE_FWD, true);
+  else FRX_IGEMM_TILE(MODE_FWD, false);
+#undef FRX_IGEMM_TILE
+#undef FRX_IGEMM
   FRX_LAUNCH_CHECK();
   return FRX_OK;
 }
@@ -77,6 +88,7 @@ extern "C" int frx_conv_fwd(int device, frx_stream_t stream, const frx_conv_desc
   FRX_CHECK_ARG(x && w && y, "conv_fwd: NULL pointer");
   FRX_CHECK_ARG(!(d->stem && in_scale), "conv_fwd: the stem takes the raw image (no prologue)");
   FRX_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "conv_fwd: in_scale/in_shift must come together");
+  FRX_CHECK_ARG(!in_scale || d->Ci <= 2048, "conv_fwd: BN prologue supports up to 2048 input channels (got %d)", d->Ci);
   FRX_ENTER(device);
   ConvArgs a{};
   a.X = x; a.W = w; a.Y = y;

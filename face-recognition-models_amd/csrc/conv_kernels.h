@@ -14,6 +14,7 @@
 //         k order inside a chunk is permuted identically for A and B, which a sum allows)
 #pragma once
 #include "frx_common.h"
+#include <type_traits>
 
 namespace frx {
 
@@ -51,6 +52,32 @@ __device__ __forceinline__ int swz64(int row) { return (0x1320 >> (((row >> 2) &
 // N range, chosen so fragments (2a, 2a+1) give a lane 8 consecutive channels (see the epilogue).
 __device__ __forceinline__ int chan_of(int j, int fr) { return 32 * (j >> 1) + 8 * (fr >> 2) + 4 * (j & 1) + (fr & 3); }
 
+// Sum N values per lane over the 16 lanes of a DPP row with a halving butterfly: each step a lane keeps
+// half of its values (chosen by one bit of its index) and adds the partner's copy of that half.
+// Afterwards lane fr holds the 16-lane total of value index (fr % N) in v[0].  Everything is indexed
+// at compile time (runtime-indexed register arrays turn into select chains or scratch).
+template <int N, int BIT>
+__device__ __forceinline__ void lane16_butterfly(float* vs, float* vq, int fr) {
+  if constexpr (BIT >= 1) {
+    if constexpr (N > BIT) {
+      constexpr int H = N / 2;
+      const bool up = (fr & BIT) != 0;
+#pragma unroll
+      for (int e = 0; e < H; ++e) {
+        const float ks = up ? vs[e + H] : vs[e], ss = up ? vs[e] : vs[e + H];
+        const float kq = up ? vq[e + H] : vq[e], sq = up ? vq[e] : vq[e + H];
+        vs[e] = ks + __shfl_xor(ss, BIT, 64);
+        vq[e] = kq + __shfl_xor(sq, BIT, 64);
+      }
+      lane16_butterfly<H, BIT / 2>(vs, vq, fr);
+    } else {
+#pragma unroll
+      for (int e = 0; e < N; ++e) { vs[e] += __shfl_xor(vs[e], BIT, 64); vq[e] += __shfl_xor(vq[e], BIT, 64); }
+      lane16_butterfly<N, BIT / 2>(vs, vq, fr);
+    }
+  }
+}
+
 template <typename T>
 __device__ __forceinline__ uint4 bn_relu_vec(uint4 raw, const float* __restrict__ sc,
                                              const float* __restrict__ sh, int relu) {
@@ -87,14 +114,21 @@ template <typename T> __device__ __forceinline__ float load_as_float(const void*
 // forward / dgrad / stem: BM x BN output tile, 4 waves as WM x WN, double-buffered LDS,
 // one barrier per K-chunk, global loads of chunk k+1 in flight under the MFMAs of chunk k.
 // ------------------------------------------------------------------------------------------
-template <typename T, int BM, int BN, int WM, int WN>
-__global__ __launch_bounds__(256) void k_igemm(ConvArgs a) {
+// MODE (gather geometry) and PRO (BN+ReLU prologue) are compile-time so the steady-state K loop is
+// straight-line code: hipcc then keeps counted s_waitcnt vmcnt(N) for the register ring.
+template <typename T, int BM, int BN, int WM, int WN, int MODE, bool PRO>
+__global__ __launch_bounds__(256, 2) void k_igemm(ConvArgs a) {   // 2 waves/SIMD: <= 256 VGPR+AGPR
   constexpr int VEC = TT<T>::VEC, CE = TT<T>::CE;
   constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 16, FN = WTN / 16;
   constexpr int ALD = BM / 64, BLD = BN / 64;
   constexpr int STAGE = (BM + BN) * 64;
   static_assert(WM * WN == 4 && WTM % 16 == 0 && WTN % 16 == 0, "bad wave tiling");
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  // BN scale/shift of the input channels live in LDS: fetching them from global memory at commit
+  // time would be the NEWEST vector-memory op and force vmcnt(0), draining the prefetch ring.
+  constexpr int PRO_MAXC = 2048;
+  __shared__ __attribute__((aligned(16))) float s_scale[PRO ? PRO_MAXC : 4];
+  __shared__ __attribute__((aligned(16))) float s_shift[PRO ? PRO_MAXC : 4];
 
   // XCD-aware tile order: blocks that share an A row-panel (same mt) share an XCD's L2.
   const int bid = blockIdx.x;
@@ -109,8 +143,8 @@ __global__ __launch_bounds__(256) void k_igemm(ConvArgs a) {
   const T* __restrict__ X = reinterpret_cast<const T*>(a.X);
   const T* __restrict__ Wp = reinterpret_cast<const T*>(a.W);
   const int Ktot = a.R * a.S * a.Kc;
-  const int nk = (a.mode == MODE_STEM) ? (a.R * 32) / CE : Ktot / CE;
-  const int ldw = (a.mode == MODE_STEM) ? a.R * 32 : Ktot;   // weight row length in elements
+  const int nk = (MODE == MODE_STEM) ? (a.R * 32) / CE : Ktot / CE;
+  const int ldw = (MODE == MODE_STEM) ? a.R * 32 : Ktot;   // weight row length in elements
 
   // ---- per-thread gather bookkeeping (rows fixed across the K loop)
   int rn[ALD], rh[ALD], rw[ALD];
@@ -124,8 +158,8 @@ __global__ __launch_bounds__(256) void k_igemm(ConvArgs a) {
     const int n = mm / hw, rem = mm - n * hw;
     const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
     rn[i] = n;
-    if (a.mode == MODE_FWD) { rh[i] = oh * a.stride - a.pad; rw[i] = ow * a.stride - a.pad; }
-    else if (a.mode == MODE_DGRAD) { rh[i] = oh + a.pad; rw[i] = ow + a.pad; }
+    if (MODE == MODE_FWD) { rh[i] = oh * a.stride - a.pad; rw[i] = ow * a.stride - a.pad; }
+    else if (MODE == MODE_DGRAD) { rh[i] = oh + a.pad; rw[i] = ow + a.pad; }
     else { rh[i] = oh * 2; rw[i] = ow * 2; }
   }
   const T* bptr[BLD];
@@ -137,55 +171,89 @@ __global__ __launch_bounds__(256) void k_igemm(ConvArgs a) {
     bptr[i] = Wp + (long)(bok[i] ? n : 0) * ldw + chunk * VEC;
   }
 
+  if constexpr (PRO) {
+    for (int c = tid; c < a.Kc; c += 256) { s_scale[c] = a.in_scale[c]; s_shift[c] = a.in_shift[c]; }
+    __syncthreads();
+  }
   int tr = 0, ts = 0, c0 = 0;   // current tap (r, s) and channel offset of the K-chunk
-  uint4 ra[ALD], rb[BLD];
+  // Register ring of PD K-chunks: HBM/L2 latency (~2k cycles under load) is several chunks of MFMA work,
+  // so loads run PD-1 chunks ahead of the LDS write that consumes them.
+  constexpr int PD = 3;
+  uint4 ra[PD][ALD], rb[PD][BLD];
+  int rc0[PD];                  // channel offset each ring slot was loaded at (for the BN prologue)
+  unsigned rmask[PD];           // which of the slot's A rows were in bounds (padding stays exactly 0)
+  const T* aptr[ALD];           // gathered pixel of the CURRENT tap (channel 0) per staged row
+  bool aok[ALD];
 
-  auto load_chunk = [&](int kc) {
+  // Address arithmetic and bounds checks run once per tap, not once per K-chunk: inside a tap the
+  // gather only walks along the channel axis.
+  auto set_tap = [&]() {
 #pragma unroll
     for (int i = 0; i < ALD; ++i) {
       bool ok = rok[i];
       long off;
-      if (a.mode == MODE_FWD) {
+      if (MODE == MODE_FWD) {
         const int hi = rh[i] + tr, wi = rw[i] + ts;
         ok = ok && (unsigned)hi < (unsigned)a.Hx && (unsigned)wi < (unsigned)a.Wx;
-        off = (((long)rn[i] * a.Hx + hi) * a.Wx + wi) * a.Kc + c0 + chunk * VEC;
-      } else if (a.mode == MODE_DGRAD) {
+        off = (((long)rn[i] * a.Hx + hi) * a.Wx + wi) * a.Kc;
+      } else if (MODE == MODE_DGRAD) {
         const int th = rh[i] - tr, tw = rw[i] - ts;
         const int sm = a.stride - 1, sh = a.stride >> 1;   // stride is 1 or 2
         ok = ok && th >= 0 && tw >= 0 && ((th & sm) == 0) && ((tw & sm) == 0);
         const int hi = th >> sh, wi = tw >> sh;
         ok = ok && hi < a.Hx && wi < a.Wx;
-        off = (((long)rn[i] * a.Hx + hi) * a.Wx + wi) * a.Kc + c0 + chunk * VEC;
+        off = (((long)rn[i] * a.Hx + hi) * a.Wx + wi) * a.Kc;
       } else {  // stem: physically padded NHWC4 input, row tr, 8 taps x 4 channels = 32 elements
-        off = (((long)rn[i] * a.Hx + rh[i] + tr) * a.Wx + rw[i]) * 4 + c0 + chunk * VEC;
+        off = (((long)rn[i] * a.Hx + rh[i] + tr) * a.Wx + rw[i]) * 4;
       }
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ok) {
-        v = *reinterpret_cast<const uint4*>(X + off);
-        if (a.in_scale) v = bn_relu_vec<T>(v, a.in_scale + c0 + chunk * VEC, a.in_shift + c0 + chunk * VEC, a.in_relu);
-      }
-      ra[i] = v;
+      aok[i] = ok;
+      aptr[i] = X + (ok ? off : 0) + chunk * VEC;   // out-of-bounds rows read pixel 0 and are zeroed at commit
     }
+  };
+  set_tap();
+
+  // issue the global loads of chunk kc into ring slot `slot` (no transform yet: nothing waits here)
+  auto issue_chunk = [&](int kc, auto slot_tag) {
+    constexpr int slot = decltype(slot_tag)::value;
+    rc0[slot] = c0;
+    unsigned m = 0;
+#pragma unroll
+    for (int i = 0; i < ALD; ++i) {
+      // UNCONDITIONAL load (a predicated one makes hipcc branch around it and wait vmcnt(0) per chunk)
+      ra[slot][i] = *reinterpret_cast<const uint4*>(aptr[i] + c0);
+      m |= (aok[i] ? 1u : 0u) << i;
+    }
+    rmask[slot] = m;
 #pragma unroll
     for (int i = 0; i < BLD; ++i)
-      rb[i] = bok[i] ? *reinterpret_cast<const uint4*>(bptr[i] + (long)kc * CE) : make_uint4(0, 0, 0, 0);
+      rb[slot][i] = *reinterpret_cast<const uint4*>(bptr[i] + (long)kc * CE);
     // advance the tap walker to chunk kc+1
     c0 += CE;
-    const int span = (a.mode == MODE_STEM) ? 32 : a.Kc;
-    if (c0 >= span) { c0 = 0; if (a.mode == MODE_STEM) { ++tr; } else if (++ts == a.S) { ts = 0; ++tr; } }
+    const int span = (MODE == MODE_STEM) ? 32 : a.Kc;
+    if (c0 >= span) {
+      c0 = 0;
+      if (MODE == MODE_STEM) { ++tr; } else if (++ts == a.S) { ts = 0; ++tr; }
+      if (kc + 1 < nk) set_tap();
+    }
   };
-  auto store_chunk = [&](int buf) {
+  // BN+ReLU prologue, then registers -> LDS stage `buf`
+  auto commit_chunk = [&](int buf, auto slot_tag) {
+    constexpr int slot = decltype(slot_tag)::value;
     char* As = smem + buf * STAGE;
     char* Bs = As + BM * 64;
 #pragma unroll
     for (int i = 0; i < ALD; ++i) {
+      uint4 v = ra[slot][i];
+      if constexpr (PRO)
+        v = bn_relu_vec<T>(v, s_scale + rc0[slot] + chunk * VEC, s_shift + rc0[slot] + chunk * VEC, a.in_relu);
+      if (!((rmask[slot] >> i) & 1u)) v = make_uint4(0, 0, 0, 0);      // padding is exactly zero AFTER the prologue
       const int row = srow + 64 * i;
-      *reinterpret_cast<uint4*>(As + (row * 4 + (chunk ^ swz64(row))) * 16) = ra[i];
+      *reinterpret_cast<uint4*>(As + (row * 4 + (chunk ^ swz64(row))) * 16) = v;
     }
 #pragma unroll
     for (int i = 0; i < BLD; ++i) {
       const int row = srow + 64 * i;
-      *reinterpret_cast<uint4*>(Bs + (row * 4 + (chunk ^ swz64(row))) * 16) = rb[i];
+      *reinterpret_cast<uint4*>(Bs + (row * 4 + (chunk ^ swz64(row))) * 16) = bok[i] ? rb[slot][i] : make_uint4(0, 0, 0, 0);
     }
   };
 
@@ -195,13 +263,8 @@ __global__ __launch_bounds__(256) void k_igemm(ConvArgs a) {
 #pragma unroll
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  load_chunk(0);
-  store_chunk(0);
-  __syncthreads();
   const int fr = lane & 15, fq = lane >> 4;
-  for (int kc = 0; kc < nk; ++kc) {
-    const int cur = kc & 1;
-    if (kc + 1 < nk) load_chunk(kc + 1);
+  auto compute_chunk = [&](int cur) {
     const char* As = smem + cur * STAGE;
     const char* Bs = As + BM * 64;
     uint4 fa[FM], fb[FN];
@@ -232,8 +295,55 @@ __global__ __launch_bounds__(256) void k_igemm(ConvArgs a) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(pb[q], pa[q], acc[i][j], 0, 0, 0);
         }
       }
-    if (kc + 1 < nk) store_chunk(cur ^ 1);
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  static_assert(PD == 3, "the ring below is written out for 3 slots");
+  issue_chunk(0, S0{});
+  if (1 < nk) issue_chunk(1, S1{});
+  if (2 < nk) issue_chunk(2, S2{});
+  commit_chunk(0, S0{});
+  __syncthreads();
+  // chunk j lives in ring slot j % 3 and in LDS stage j & 1.
+  // Steady state: no branch between a load's issue and its wait, so hipcc keeps counted vmcnt(N) waits.
+  int kc = 0;
+  for (; kc + 5 < nk; kc += 3) {
+    compute_chunk(kc & 1);
+    issue_chunk(kc + 3, S0{});
+    commit_chunk((kc + 1) & 1, S1{});
     __syncthreads();
+    compute_chunk((kc + 1) & 1);
+    issue_chunk(kc + 4, S1{});
+    commit_chunk((kc + 2) & 1, S2{});
+    __syncthreads();
+    compute_chunk((kc + 2) & 1);
+    issue_chunk(kc + 5, S2{});
+    commit_chunk((kc + 3) & 1, S0{});
+    __syncthreads();
+  }
+  for (; kc < nk; kc += 3) {                  // tail (and the whole loop when K is short)
+    {
+      const int k = kc;
+      compute_chunk(k & 1);
+      if (k + 3 < nk) issue_chunk(k + 3, S0{});
+      if (k + 1 < nk) commit_chunk((k + 1) & 1, S1{});
+      __syncthreads();
+    }
+    if (kc + 1 < nk) {
+      const int k = kc + 1;
+      compute_chunk(k & 1);
+      if (k + 3 < nk) issue_chunk(k + 3, S1{});
+      if (k + 1 < nk) commit_chunk((k + 1) & 1, S2{});
+      __syncthreads();
+    }
+    if (kc + 2 < nk) {
+      const int k = kc + 2;
+      compute_chunk(k & 1);
+      if (k + 3 < nk) issue_chunk(k + 3, S2{});
+      if (k + 1 < nk) commit_chunk((k + 1) & 1, S0{});
+      __syncthreads();
+    }
   }
 
   // ---- epilogue.  C/D map: col = lane&15 (pixel), row = (lane>>4)*4 + reg (channel slot).
@@ -248,9 +358,11 @@ __global__ __launch_bounds__(256) void k_igemm(ConvArgs a) {
   for (int a2 = 0; a2 < FN / 2; ++a2) {
     const int nb = n0 + wn * WTN + 32 * a2 + 8 * fq;          // first of this lane's 8 channels
     const bool nok = nb < a.Ncol;                              // Ncol % 8 == 0 (checked on the host)
-    float bias[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) bias[e] = (a.bias && nok) ? a.bias[nb + e] : 0.f;
+    float bias[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (a.bias != nullptr && nok) {
+      const float4 b0 = *reinterpret_cast<const float4*>(a.bias + nb), b1 = *reinterpret_cast<const float4*>(a.bias + nb + 4);
+      bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w; bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const int m = m0 + wm * WTM + i * 16 + fr;
@@ -303,29 +415,7 @@ __global__ __launch_bounds__(256) void k_igemm(ConvArgs a) {
     for (int j = 0; j < FN; ++j)
 #pragma unroll
       for (int r = 0; r < 4; ++r) { vs[j * 4 + r] = csum[j][r]; vq[j * 4 + r] = csq[j][r]; }
-    int nv = NV;
-#pragma unroll
-    for (int bit = 8; bit >= 1; bit >>= 1) {
-      if (nv > bit) {        // halve: keep the half selected by this lane's bit, add the partner's
-        const bool up = (fr & bit) != 0;
-        const int h = nv / 2;
-#pragma unroll
-        for (int e = 0; e < NV / 2; ++e) {
-          if (e < h) {
-            const float ks = up ? vs[e + h] : vs[e], ss = up ? vs[e] : vs[e + h];
-            const float kq = up ? vq[e + h] : vq[e], sq = up ? vq[e] : vq[e + h];
-            vs[e] = ks + __shfl_xor(ss, bit, 64);
-            vq[e] = kq + __shfl_xor(sq, bit, 64);
-          }
-        }
-        nv = h;
-      } else {               // fewer values than lanes on this bit: plain all-reduce step
-#pragma unroll
-        for (int e = 0; e < NV; ++e) {
-          if (e < nv) { vs[e] += __shfl_xor(vs[e], bit, 64); vq[e] += __shfl_xor(vq[e], bit, 64); }
-        }
-      }
-    }
+    lane16_butterfly<NV, 8>(vs, vq, fr);
     // lane fr now owns value index vi = fr % NV  ->  fragment j = vi>>2, reg r = vi&3
     float* red = reinterpret_cast<float*>(smem);   // [2][WM][BN]; the K loop ended with a barrier
     if (fr < NV) {
