@@ -161,13 +161,22 @@ extern "C" int frx_conv_wgrad(int device, frx_stream_t stream, const frx_conv_de
   a.splits = splits;
   dim3 grid(a.tilesCo * a.tilesCi * taps * splits), block(256);
   hipStream_t st = (hipStream_t)stream;
+  const int wmode = d->stem ? WG_STEM : ((d->R == 1 && d->S == 1 && d->stride == 1) ? WG_POINTWISE : WG_GENERAL);
+  const bool pro = in_scale != nullptr;
+#define FRX_WG(T_, BT_, WM_, PRO_) hipLaunchKernelGGL((k_wgrad<T_, BT_, WM_, PRO_>), grid, block, 0, st, a)
+#define FRX_WG_MODE(T_, BT_)                                              \
+  do {                                                                    \
+    if (wmode == WG_STEM) FRX_WG(T_, BT_, WG_STEM, false);                \
+    else if (wmode == WG_POINTWISE) { if (pro) FRX_WG(T_, BT_, WG_POINTWISE, true); else FRX_WG(T_, BT_, WG_POINTWISE, false); } \
+    else { if (pro) FRX_WG(T_, BT_, WG_GENERAL, true); else FRX_WG(T_, BT_, WG_GENERAL, false); }                               \
+  } while (0)
   if (d->dtype == FRX_BF16) {
-    if (bt == 64) hipLaunchKernelGGL((k_wgrad<bf16_t, 64>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((k_wgrad<bf16_t, 128>), grid, block, 0, st, a);
+    if (bt == 64) FRX_WG_MODE(bf16_t, 64); else FRX_WG_MODE(bf16_t, 128);
   } else {
-    if (bt == 64) hipLaunchKernelGGL((k_wgrad<float, 64>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((k_wgrad<float, 128>), grid, block, 0, st, a);
+    if (bt == 64) FRX_WG_MODE(float, 64); else FRX_WG_MODE(float, 128);
   }
+#undef FRX_WG_MODE
+#undef FRX_WG
   FRX_LAUNCH_CHECK();
   return FRX_OK;
 }

@@ -464,15 +464,21 @@ template <int RB> __device__ __forceinline__ int tr_swz(int row) {
   else return ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 5);
 }
 
-template <typename T, int BT>   // BT x BT output tile (co x ci)
-__global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
+enum { WG_POINTWISE = 0, WG_GENERAL = 1, WG_STEM = 2 };
+
+// WMODE: gather geometry of the X operand (compile-time: keeps the K loop straight-line so the
+// register ring gets counted vmcnt waits).  PRO: BN+ReLU prologue on X; a thread's channel group
+// is the same for every chunk, so its 8 scale / 8 shift values stay in registers.
+template <typename T, int BT, int WMODE, bool PRO>   // BT x BT output tile (co x ci)
+__global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
   constexpr int VEC = TT<T>::VEC;
   constexpr int KP = (sizeof(T) == 2) ? 32 : 16;   // pixels per K-chunk
   constexpr int RB = BT * sizeof(T);               // bytes per pixel row of a tile
   constexpr int CPR = RB / 16;                     // 16-byte chunks per row
   constexpr int LD = (KP * CPR) / 256;             // 16-byte loads per thread per operand
   constexpr int WT = BT / 2, F = WT / 16;          // 2x2 waves
-  static_assert(LD >= 1, "tile too small");
+  constexpr int PD = 3;                            // register ring depth (chunks in flight)
+  static_assert(LD >= 1 && 256 % CPR == 0, "tile shape");
   __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KP * RB];
 
   // 1-D grid, split index fastest: blocks that stream the SAME pixel range (same split, other
@@ -488,66 +494,81 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
   const int kbeg = split * a.chunks_per_split;
   const int kend = min(nchunks, kbeg + a.chunks_per_split);
   if (kbeg >= kend) return;
+  const int nk = kend - kbeg;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const T* __restrict__ X = reinterpret_cast<const T*>(a.X);
   const T* __restrict__ dY = reinterpret_cast<const T*>(a.dY);
   const int hw = a.Ho * a.Wo;
-  const int xch = a.stem ? 32 : a.Ci;   // channels (elements) addressable in the X row for this tap-row
-  const bool pointwise = !a.stem && a.R == 1 && a.S == 1 && a.stride == 1;
+  const int xch = (WMODE == WG_STEM) ? 32 : a.Ci;   // elements addressable in the X row for this tap
   const float inv_hw = 1.0f / (float)hw, inv_wo = 1.0f / (float)a.Wo;
 
-  uint4 ry[LD], rx[LD];
-  auto load_chunk = [&](int kc) {
+  // fixed per thread: its 16-byte column and its first row inside a chunk (row step 256/CPR per load)
+  const int ch = tid % CPR, row0 = tid / CPR;
+  constexpr int RSTEP = 256 / CPR;
+  const int co = co0 + ch * VEC, ci = ci0 + ch * VEC;
+  const bool cook = co < a.Co, ciok = ci < xch;
+  const T* ycol = dY + (cook ? co : 0);
+  const T* xcol = X + (ciok ? ci : 0);
+  float psc[VEC], psh[VEC];
+  if constexpr (PRO) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) { psc[j] = ciok ? a.in_scale[ci + j] : 0.f; psh[j] = ciok ? a.in_shift[ci + j] : 0.f; }
+  }
+
+  uint4 ry[PD][LD], rx[PD][LD];
+  unsigned rmask[PD];     // bit i: dY row valid, bit 8+i: X row valid (zero-filled at commit otherwise)
+
+  auto issue_chunk = [&](int kc, auto slot_tag) {
+    constexpr int slot = decltype(slot_tag)::value;
+    unsigned msk = 0;
 #pragma unroll
     for (int i = 0; i < LD; ++i) {
-      const int idx = tid + 256 * i;
-      const int row = idx / CPR, ch = idx % CPR;
-      const int m = kc * KP + row;
+      const int m = kc * KP + row0 + RSTEP * i;
       const bool mok = m < a.M;
-      // dY tile
-      const int co = co0 + ch * VEC;
-      ry[i] = (mok && co < a.Co) ? *reinterpret_cast<const uint4*>(dY + (long)m * a.Co + co) : make_uint4(0, 0, 0, 0);
-      // X tile (gathered at this tap)
-      const int ci = ci0 + ch * VEC;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (mok && ci < xch) {
-        if (pointwise) {                      // 1x1 stride 1: the input pixel IS the output pixel
-          v = *reinterpret_cast<const uint4*>(X + (long)m * a.Ci + ci);
-          if (a.in_scale) v = bn_relu_vec<T>(v, a.in_scale + ci, a.in_shift + ci, a.in_relu);
+      const int mc = mok ? m : 0;
+      ry[slot][i] = *reinterpret_cast<const uint4*>(ycol + (long)mc * a.Co);       // unconditional (clamped) loads
+      long xoff;
+      bool xok = mok && ciok;
+      if constexpr (WMODE == WG_POINTWISE) {
+        xoff = (long)mc * a.Ci;                                                    // input pixel == output pixel
+      } else {
+        int n = (int)((float)mc * inv_hw);                                         // exact after one correction (m < 2^24)
+        int rem = mc - n * hw;
+        if (rem < 0) { --n; rem += hw; } else if (rem >= hw) { ++n; rem -= hw; }
+        int oh = (int)((float)rem * inv_wo);
+        int ow = rem - oh * a.Wo;
+        if (ow < 0) { --oh; ow += a.Wo; } else if (ow >= a.Wo) { ++oh; ow -= a.Wo; }
+        if constexpr (WMODE == WG_STEM) {
+          xoff = (((long)n * a.Hx + oh * 2 + tr_) * a.Wx + ow * 2) * 4;
         } else {
-          int n = (int)((float)m * inv_hw);   // exact after one correction for m < 2^24
-          int rem = m - n * hw;
-          if (rem < 0) { --n; rem += hw; } else if (rem >= hw) { ++n; rem -= hw; }
-          int oh = (int)((float)rem * inv_wo);
-          int ow = rem - oh * a.Wo;
-          if (ow < 0) { --oh; ow += a.Wo; } else if (ow >= a.Wo) { ++oh; ow -= a.Wo; }
-          if (a.stem) {
-            const long off = (((long)n * a.Hx + oh * 2 + tr_) * a.Wx + ow * 2) * 4 + ci;
-            v = *reinterpret_cast<const uint4*>(X + off);
-          } else {
-            const int hi = oh * a.stride - a.pad + tr_, wi = ow * a.stride - a.pad + ts_;
-            if ((unsigned)hi < (unsigned)a.Hx && (unsigned)wi < (unsigned)a.Wx) {
-              v = *reinterpret_cast<const uint4*>(X + (((long)n * a.Hx + hi) * a.Wx + wi) * a.Ci + ci);
-              if (a.in_scale) v = bn_relu_vec<T>(v, a.in_scale + ci, a.in_shift + ci, a.in_relu);
-            }
-          }
+          const int hi = oh * a.stride - a.pad + tr_, wi = ow * a.stride - a.pad + ts_;
+          const bool in = (unsigned)hi < (unsigned)a.Hx && (unsigned)wi < (unsigned)a.Wx;
+          xok = xok && in;
+          xoff = in ? (((long)n * a.Hx + hi) * a.Wx + wi) * a.Ci : 0;
         }
       }
-      rx[i] = v;
+      rx[slot][i] = *reinterpret_cast<const uint4*>(xcol + xoff);
+      msk |= ((mok && cook) ? 1u : 0u) << i;
+      msk |= (xok ? 1u : 0u) << (8 + i);
     }
+    rmask[slot] = msk;
   };
-  auto store_chunk = [&](int buf) {
+  auto commit_chunk = [&](int buf, auto slot_tag) {
+    constexpr int slot = decltype(slot_tag)::value;
     char* Ys = smem + buf * (2 * KP * RB);
     char* Xs = Ys + KP * RB;
 #pragma unroll
     for (int i = 0; i < LD; ++i) {
-      const int idx = tid + 256 * i;
-      const int row = idx / CPR, ch = idx % CPR;
+      const int row = row0 + RSTEP * i;
       const int off = row * RB + ((ch * 16) ^ (sizeof(T) == 2 ? tr_swz<RB>(row) : 0));
-      *reinterpret_cast<uint4*>(Ys + off) = ry[i];
-      *reinterpret_cast<uint4*>(Xs + off) = rx[i];
+      uint4 vy = ry[slot][i], vx = rx[slot][i];
+      if constexpr (PRO) vx = bn_relu_vec<T>(vx, psc, psh, a.in_relu);
+      if (!((rmask[slot] >> i) & 1u)) vy = make_uint4(0, 0, 0, 0);
+      if (!((rmask[slot] >> (8 + i)) & 1u)) vx = make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(Ys + off) = vy;
+      *reinterpret_cast<uint4*>(Xs + off) = vx;
     }
   };
 
@@ -557,13 +578,8 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < F; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  load_chunk(kbeg);
-  store_chunk(0);
-  __syncthreads();
   const int fr = lane & 15, fq = lane >> 4;
-  for (int kc = kbeg; kc < kend; ++kc) {
-    const int cur = (kc - kbeg) & 1;
-    if (kc + 1 < kend) load_chunk(kc + 1);
+  auto compute_chunk = [&](int cur) {
     const char* Ys = smem + cur * (2 * KP * RB);
     const char* Xs = Ys + KP * RB;
     if constexpr (sizeof(T) == 2) {
@@ -612,11 +628,55 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ya[i], xb[j], acc[i][j], 0, 0, 0);
       }
     }
-    if (kc + 1 < kend) store_chunk(cur ^ 1);
+  };
+
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  using S2 = std::integral_constant<int, 2>;
+  static_assert(PD == 3, "ring written out for 3 slots");
+  // chunk j (relative to kbeg) lives in ring slot j % 3 and LDS stage j & 1
+  issue_chunk(kbeg, S0{});
+  if (1 < nk) issue_chunk(kbeg + 1, S1{});
+  if (2 < nk) issue_chunk(kbeg + 2, S2{});
+  commit_chunk(0, S0{});
+  __syncthreads();
+  int j = 0;
+  for (; j + 5 < nk; j += 3) {                 // steady state: no branch between issue and wait
+    compute_chunk(j & 1);
+    issue_chunk(kbeg + j + 3, S0{});
+    commit_chunk((j + 1) & 1, S1{});
+    __syncthreads();
+    compute_chunk((j + 1) & 1);
+    issue_chunk(kbeg + j + 4, S1{});
+    commit_chunk((j + 2) & 1, S2{});
+    __syncthreads();
+    compute_chunk((j + 2) & 1);
+    issue_chunk(kbeg + j + 5, S2{});
+    commit_chunk((j + 3) & 1, S0{});
     __syncthreads();
   }
+  for (; j < nk; j += 3) {
+    {
+      compute_chunk(j & 1);
+      if (j + 3 < nk) issue_chunk(kbeg + j + 3, S0{});
+      if (j + 1 < nk) commit_chunk((j + 1) & 1, S1{});
+      __syncthreads();
+    }
+    if (j + 1 < nk) {
+      compute_chunk((j + 1) & 1);
+      if (j + 4 < nk) issue_chunk(kbeg + j + 4, S1{});
+      if (j + 2 < nk) commit_chunk((j + 2) & 1, S2{});
+      __syncthreads();
+    }
+    if (j + 2 < nk) {
+      compute_chunk((j + 2) & 1);
+      if (j + 5 < nk) issue_chunk(kbeg + j + 5, S2{});
+      if (j + 3 < nk) commit_chunk((j + 3) & 1, S0{});
+      __syncthreads();
+    }
+  }
 
-  const int ldw = a.stem ? 32 : a.Ci;           // elements per (co, r, s-row) line of dW
+  const int ldw = (WMODE == WG_STEM) ? 32 : a.Ci;   // elements per (co, r, s-row) line of dW
   const bool atomic = a.splits > 1;
 #pragma unroll
   for (int i = 0; i < F; ++i)
@@ -627,7 +687,7 @@ __global__ __launch_bounds__(256) void k_wgrad(WgradArgs a) {
       for (int r = 0; r < 4; ++r) {
         const int co = co0 + wr * WT + i * 16 + fq * 4 + r;
         if (co < a.Co && ci < ldw) {
-          const long o = a.stem ? (((long)co * a.R + tr_) * 32 + ci)
+          const long o = (WMODE == WG_STEM) ? (((long)co * a.R + tr_) * 32 + ci)
                                 : ((((long)co * a.R + tr_) * a.S + ts_) * a.Ci + ci);
           if (atomic) atomicAdd(a.dW + o, acc[i][j][r]); else a.dW[o] += acc[i][j][r];
         }
