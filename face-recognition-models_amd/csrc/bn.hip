@@ -202,9 +202,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(long rows, int C, const T
   }
 }
 
-// partial [nblk][2][C] -> dgamma += , dbeta += , coef[0]=gamma*invstd, coef[1]=sum(dz)/M, coef[2]=sum(dz*xhat)/M
+// partial [nblk][2][C] -> dgamma += , dbeta += , coef [3][C] = (alpha, beta, gam) with dy = alpha*dz + beta*y + gam
 __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict__ partial, int nblk, int C,
                                                          double count, const float* __restrict__ gamma,
+                                                         const float* __restrict__ mean,
                                                          const float* __restrict__ invstd,
                                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                          float* __restrict__ coef) {
@@ -214,9 +215,13 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict
   if (threadIdx.x >= 16 || c >= C) return;
   if (dbeta) dbeta[c] += (float)a;
   if (dgamma) dgamma[c] += (float)b;
-  coef[c] = gamma[c] * invstd[c];
-  coef[C + c] = (float)(a / count);
-  coef[2 * C + c] = (float)(b / count);
+  // dy = k1*(dz - c1 - xhat*c2), xhat = (y-mu)*is   ==   alpha*dz + beta*y + gam   (affine in dz and y)
+  const double k1 = (double)gamma[c] * (double)invstd[c];
+  const double c1 = a / count, c2 = b / count;
+  const double is = (double)invstd[c], mu = (double)mean[c];
+  coef[c] = (float)k1;
+  coef[C + c] = (float)(-k1 * is * c2);
+  coef[2 * C + c] = (float)(k1 * (mu * is * c2 - c1));
 }
 
 // dy = k1 * (dz - c1 - xhat*c2);  dz = g*mask with the same mask rule as the reduce kernel
@@ -232,11 +237,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(long rows, int C, const T*
   const RowWalk w(C, V);
   for (int g0 = 0; g0 < w.groups; g0 += w.gpb) {
     const int grp = g0 + w.tg, c = grp * V;
-    float k1[V], c1[V], c2[V], mu[V], is[V], sc[V], sh[V];
+    float al[V], be[V], ga[V], sc[V], sh[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) {
-      k1[j] = coef[c + j]; c1[j] = coef[C + c + j]; c2[j] = coef[2 * C + c + j];
-      mu[j] = mean[c + j]; is[j] = invstd[c + j];
+      al[j] = coef[c + j]; be[j] = coef[C + c + j]; ga[j] = coef[2 * C + c + j];
       sc[j] = (relu && !out) ? scale[c + j] : 1.f; sh[j] = (relu && !out) ? shift[c + j] : 0.f;
     }
     for (long r = (long)blockIdx.x * w.rpp + w.trow; r < rows; r += (long)gridDim.x * w.rpp) {
@@ -252,7 +256,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(long rows, int C, const T*
         if (out) on = vo.get(j) > 0.f;
         else if (relu) on = fmaf(yy, sc[j], sh[j]) > 0.f;
         const float dz = on ? vg.get(j) : 0.f;
-        vd.set(j, k1[j] * (dz - c1[j] - (yy - mu[j]) * is[j] * c2[j]));
+        vd.set(j, fmaf(al[j], dz, fmaf(be[j], yy, ga[j])));
       }
       reinterpret_cast<uint4*>(dy)[i] = vd.raw;
     }
@@ -463,12 +467,12 @@ extern "C" int frx_bn_bwd_reduce(int device, frx_stream_t stream, int dtype, int
 }
 
 extern "C" int frx_bn_bwd_finalize(int device, frx_stream_t stream, const float* partial, int nblk, int C,
-                                   int64_t count, const float* gamma, const float* invstd, float* dgamma,
-                                   float* dbeta, float* coef) {
-  FRX_CHECK_ARG(partial && gamma && invstd && coef && nblk > 0 && C > 0 && count > 0, "bn_bwd_finalize: bad args");
+                                   int64_t count, const float* gamma, const float* mean, const float* invstd,
+                                   float* dgamma, float* dbeta, float* coef) {
+  FRX_CHECK_ARG(partial && gamma && mean && invstd && coef && nblk > 0 && C > 0 && count > 0, "bn_bwd_finalize: bad args");
   FRX_ENTER(device);
   hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, partial, nblk, C,
-                     (double)count, gamma, invstd, dgamma, dbeta, coef);
+                     (double)count, gamma, mean, invstd, dgamma, dbeta, coef);
   FRX_LAUNCH_CHECK();
   return FRX_OK;
 }

@@ -30,10 +30,10 @@ static int launch_igemm(hipStream_t st, ConvArgs a) {
     else if (c.bm == 128 && c.bn == 64) FRX_IGEMM(128, 64, MODE_, PRO_); \
     else FRX_IGEMM(64, 64, MODE_, PRO_);                              \
   } while (0)
-  if (a.mode == MODE_STEM) FRX_IGEMM_TILE(MODE_STEM, false);
-  else if (a.mode == MODE_DGRAD) FRX_IGEMM_TILE(MODE_DGRAD, false);
-  else if (a.in_scale) FRX_IGEMM_TILE(MODE_FWD, true);
-  else FRX_IGEMM_TILE(MODE_FWD, false);
+  if (a.mode == MODE_STEM) FRX_IGEMM_TILE(MODE_STEM, 0);
+  else if (a.mode == MODE_DGRAD) { if (a.X2) FRX_IGEMM_TILE(MODE_DGRAD, 2); else FRX_IGEMM_TILE(MODE_DGRAD, 0); }
+  else if (a.in_scale) FRX_IGEMM_TILE(MODE_FWD, 1);
+  else FRX_IGEMM_TILE(MODE_FWD, 0);
 #undef FRX_IGEMM_TILE
 #undef FRX_IGEMM
   FRX_LAUNCH_CHECK();
@@ -107,12 +107,11 @@ extern "C" int frx_conv_fwd(int device, frx_stream_t stream, const frx_conv_desc
   return d->dtype == FRX_BF16 ? launch_igemm<bf16_t>((hipStream_t)stream, a) : launch_igemm<float>((hipStream_t)stream, a);
 }
 
-extern "C" int frx_conv_dgrad(int device, frx_stream_t stream, const frx_conv_desc* d, const void* dy,
-                              const void* w_crsk, const void* addend, void* dx) {
+static int dgrad_impl(int device, frx_stream_t stream, const frx_conv_desc* d, const void* dy, const void* w_crsk,
+                      const void* addend, void* dx, const frx_dgrad_fuse* f) {
   if (int rc = check_conv(d)) return rc;
   FRX_CHECK_ARG(!d->stem, "conv_dgrad: the stem has no input gradient");
   FRX_CHECK_ARG(dy && w_crsk && dx, "conv_dgrad: NULL pointer");
-  FRX_ENTER(device);
   ConvArgs a{};
   a.X = dy; a.W = w_crsk; a.Y = dx; a.addend = addend;
   a.N = d->N; a.Hx = d->Ho; a.Wx = d->Wo; a.Kc = d->Co;
@@ -120,12 +119,43 @@ extern "C" int frx_conv_dgrad(int device, frx_stream_t stream, const frx_conv_de
   a.stride = d->stride; a.pad = d->pad;
   a.M = d->N * d->Hi * d->Wi;
   a.mode = MODE_DGRAD;
+  if (f) {
+    if (f->pro_y) {
+      FRX_CHECK_ARG(f->pro_coef != nullptr, "conv_dgrad_bn: pro_y needs pro_coef");
+      FRX_CHECK_ARG(d->Co <= 2048, "conv_dgrad_bn: BN prologue supports up to 2048 channels (got %d)", d->Co);
+      a.X2 = f->pro_y; a.in_scale = f->pro_coef; a.in_shift = f->pro_coef + d->Co; a.pro_gam = f->pro_coef + 2 * d->Co;
+    }
+    if (f->epi_y) {
+      FRX_CHECK_ARG(f->epi_mean && f->epi_invstd && f->epi_partial, "conv_dgrad_bn: epilogue needs mean / invstd / partial");
+      FRX_CHECK_ARG(f->epi_out || (f->epi_scale && f->epi_shift), "conv_dgrad_bn: epilogue mask needs epi_out or scale/shift");
+      a.epi_bnbwd = 1; a.e_y = f->epi_y; a.e_out = f->epi_out; a.e_scale = f->epi_scale; a.e_shift = f->epi_shift;
+      a.e_mean = f->epi_mean; a.e_invstd = f->epi_invstd; a.stat_partial = f->epi_partial;
+    }
+  }
+  FRX_ENTER(device);
   return d->dtype == FRX_BF16 ? launch_igemm<bf16_t>((hipStream_t)stream, a) : launch_igemm<float>((hipStream_t)stream, a);
 }
 
-extern "C" int frx_conv_wgrad(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x,
-                              const float* in_scale, const float* in_shift, int in_relu, const void* dy,
-                              float* dw) {
+extern "C" int frx_conv_dgrad(int device, frx_stream_t stream, const frx_conv_desc* d, const void* dy,
+                              const void* w_crsk, const void* addend, void* dx) {
+  return dgrad_impl(device, stream, d, dy, w_crsk, addend, dx, nullptr);
+}
+
+extern "C" int frx_conv_dgrad_bn(int device, frx_stream_t stream, const frx_conv_desc* d, const void* dz,
+                                 const void* w_crsk, const void* addend, void* dx, const frx_dgrad_fuse* fuse) {
+  FRX_CHECK_ARG(fuse != nullptr, "conv_dgrad_bn: fuse is NULL");
+  return dgrad_impl(device, stream, d, dz, w_crsk, addend, dx, fuse);
+}
+
+extern "C" int frx_conv_dgrad_stat_rows(const frx_conv_desc* d) {
+  if (check_conv(d) != FRX_OK) return -1;
+  const long M = (long)d->N * d->Hi * d->Wi;
+  return cdiv(M, pick_tile(M, d->Ci).bm);
+}
+
+static int wgrad_impl(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x,
+                      const float* in_scale, const float* in_shift, int in_relu, const void* dy,
+                      const void* pro_y, const float* pro_coef, float* dw) {
   if (int rc = check_conv(d)) return rc;
   FRX_CHECK_ARG(x && dy && dw, "conv_wgrad: NULL pointer");
   FRX_CHECK_ARG(!(d->stem && in_scale), "conv_wgrad: the stem takes the raw image (no prologue)");
@@ -133,6 +163,7 @@ extern "C" int frx_conv_wgrad(int device, frx_stream_t stream, const frx_conv_de
   WgradArgs a{};
   a.X = x; a.dY = dy; a.dW = dw;
   a.in_scale = in_scale; a.in_shift = in_shift; a.in_relu = in_relu;
+  a.dY2 = pro_y; a.y_coef = pro_coef;
   a.N = d->N; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co; a.R = d->R; a.S = d->S;
   a.stride = d->stride; a.pad = d->pad; a.M = d->N * d->Ho * d->Wo; a.stem = d->stem;
   int taps = d->R * d->S;
@@ -163,7 +194,12 @@ extern "C" int frx_conv_wgrad(int device, frx_stream_t stream, const frx_conv_de
   hipStream_t st = (hipStream_t)stream;
   const int wmode = d->stem ? WG_STEM : ((d->R == 1 && d->S == 1 && d->stride == 1) ? WG_POINTWISE : WG_GENERAL);
   const bool pro = in_scale != nullptr;
-#define FRX_WG(T_, BT_, WM_, PRO_) hipLaunchKernelGGL((k_wgrad<T_, BT_, WM_, PRO_>), grid, block, 0, st, a)
+  const bool ypro = pro_y != nullptr;
+#define FRX_WG(T_, BT_, WM_, PRO_)                                                                    \
+  do {                                                                                                \
+    if (ypro) hipLaunchKernelGGL((k_wgrad<T_, BT_, WM_, PRO_, true>), grid, block, 0, st, a);         \
+    else hipLaunchKernelGGL((k_wgrad<T_, BT_, WM_, PRO_, false>), grid, block, 0, st, a);             \
+  } while (0)
 #define FRX_WG_MODE(T_, BT_)                                              \
   do {                                                                    \
     if (wmode == WG_STEM) FRX_WG(T_, BT_, WG_STEM, false);                \
@@ -179,4 +215,18 @@ extern "C" int frx_conv_wgrad(int device, frx_stream_t stream, const frx_conv_de
 #undef FRX_WG
   FRX_LAUNCH_CHECK();
   return FRX_OK;
+}
+
+extern "C" int frx_conv_wgrad(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x,
+                              const float* in_scale, const float* in_shift, int in_relu, const void* dy,
+                              float* dw) {
+  return wgrad_impl(device, stream, d, x, in_scale, in_shift, in_relu, dy, nullptr, nullptr, dw);
+}
+
+extern "C" int frx_conv_wgrad_bn(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x,
+                                 const float* in_scale, const float* in_shift, int in_relu, const void* dz,
+                                 const void* pro_y, const float* pro_coef, float* dw) {
+  FRX_CHECK_ARG(pro_y && pro_coef, "conv_wgrad_bn: pro_y / pro_coef are NULL");
+  FRX_CHECK_ARG(!d || !d->stem, "conv_wgrad_bn: not for the stem");
+  return wgrad_impl(device, stream, d, x, in_scale, in_shift, in_relu, dz, pro_y, pro_coef, dw);
 }

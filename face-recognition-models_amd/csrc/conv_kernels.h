@@ -35,6 +35,15 @@ struct ConvArgs {
   const void* addend;     // optional [M][Ncol] (same dtype as Y unless out_f32): Y = acc + addend
   float* stat_partial;    // optional [tilesM][2][Ncol]: column sums / sums of squares of Y
   int out_f32;            // store Y as fp32 regardless of T
+  // PRO == 2 (dgrad): the gathered operand is the BN backward  alpha*dz + beta*y + gam  of two tensors
+  const void* X2;         //   y (raw conv output), same indexing as X (= dz); in_scale = alpha, in_shift = beta
+  const float* pro_gam;   //   gam [Kc]
+  // epi_bnbwd (dgrad): the output is the gradient w.r.t. a post-BN(-ReLU) activation; mask it, write dz and
+  // reduce  sum(dz), sum(dz*xhat)  per channel into stat_partial (what frx_bn_bwd_reduce does in a pass of its own)
+  int epi_bnbwd;
+  const void* e_y;        //   raw conv output of that BN layer, [M][Ncol]
+  const void* e_out;      //   optional: block output -> mask = out > 0 (merge ReLU); else mask = e_scale*y+e_shift > 0
+  const float* e_scale; const float* e_shift; const float* e_mean; const float* e_invstd;
   int N, Hx, Wx, Kc;      // geometry of X (Kc = its channel count)
   int Ho, Wo;             // output spatial size; M = N*Ho*Wo
   int Ncol, R, S, stride, pad;
@@ -105,6 +114,37 @@ __device__ __forceinline__ uint4 bn_relu_vec(uint4 raw, const float* __restrict_
   }
 }
 
+// alpha*dz + beta*y + gam on a 16-byte vector of each (BN backward as a prologue)
+template <typename T>
+__device__ __forceinline__ uint4 affine2_vec(uint4 rdz, uint4 ry, const float* __restrict__ al,
+                                             const float* __restrict__ be, const float* __restrict__ ga) {
+  constexpr int V = 16 / sizeof(T);
+  float a_[V], b_[V], g_[V];
+#pragma unroll
+  for (int q = 0; q < V / 4; ++q) {
+    const float4 x = *reinterpret_cast<const float4*>(al + 4 * q), y = *reinterpret_cast<const float4*>(be + 4 * q),
+                 z = *reinterpret_cast<const float4*>(ga + 4 * q);
+    a_[4 * q] = x.x; a_[4 * q + 1] = x.y; a_[4 * q + 2] = x.z; a_[4 * q + 3] = x.w;
+    b_[4 * q] = y.x; b_[4 * q + 1] = y.y; b_[4 * q + 2] = y.z; b_[4 * q + 3] = y.w;
+    g_[4 * q] = z.x; g_[4 * q + 1] = z.y; g_[4 * q + 2] = z.z; g_[4 * q + 3] = z.w;
+  }
+  if constexpr (sizeof(T) == 4) {
+    const float* d = reinterpret_cast<const float*>(&rdz);
+    const float* yy = reinterpret_cast<const float*>(&ry);
+    float4 o;
+    o.x = fmaf(a_[0], d[0], fmaf(b_[0], yy[0], g_[0])); o.y = fmaf(a_[1], d[1], fmaf(b_[1], yy[1], g_[1]));
+    o.z = fmaf(a_[2], d[2], fmaf(b_[2], yy[2], g_[2])); o.w = fmaf(a_[3], d[3], fmaf(b_[3], yy[3], g_[3]));
+    return *reinterpret_cast<uint4*>(&o);
+  } else {
+    const bf16x8 d = *reinterpret_cast<const bf16x8*>(&rdz);
+    const bf16x8 yy = *reinterpret_cast<const bf16x8*>(&ry);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)fmaf(a_[j], (float)d[j], fmaf(b_[j], (float)yy[j], g_[j]));
+    return *reinterpret_cast<uint4*>(&o);
+  }
+}
+
 template <typename T> __device__ __forceinline__ float load_as_float(const void* p, long i) {
   if constexpr (sizeof(T) == 4) return reinterpret_cast<const float*>(p)[i];
   else return (float)reinterpret_cast<const bf16_t*>(p)[i];
@@ -116,7 +156,7 @@ template <typename T> __device__ __forceinline__ float load_as_float(const void*
 // ------------------------------------------------------------------------------------------
 // MODE (gather geometry) and PRO (BN+ReLU prologue) are compile-time so the steady-state K loop is
 // straight-line code: hipcc then keeps counted s_waitcnt vmcnt(N) for the register ring.
-template <typename T, int BM, int BN, int WM, int WN, int MODE, bool PRO>
+template <typename T, int BM, int BN, int WM, int WN, int MODE, int PRO>   // PRO: 0 none, 1 BN+ReLU, 2 BN-backward affine
 __global__ __launch_bounds__(256, 2) void k_igemm(ConvArgs a) {   // 2 waves/SIMD: <= 256 VGPR+AGPR
   constexpr int VEC = TT<T>::VEC, CE = TT<T>::CE;
   constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 16, FN = WTN / 16;
@@ -129,6 +169,7 @@ __global__ __launch_bounds__(256, 2) void k_igemm(ConvArgs a) {   // 2 waves/SIM
   constexpr int PRO_MAXC = 2048;
   __shared__ __attribute__((aligned(16))) float s_scale[PRO ? PRO_MAXC : 4];
   __shared__ __attribute__((aligned(16))) float s_shift[PRO ? PRO_MAXC : 4];
+  __shared__ __attribute__((aligned(16))) float s_gam[PRO == 2 ? PRO_MAXC : 4];
 
   // XCD-aware tile order: blocks that share an A row-panel (same mt) share an XCD's L2.
   const int bid = blockIdx.x;
@@ -171,15 +212,20 @@ __global__ __launch_bounds__(256, 2) void k_igemm(ConvArgs a) {   // 2 waves/SIM
     bptr[i] = Wp + (long)(bok[i] ? n : 0) * ldw + chunk * VEC;
   }
 
-  if constexpr (PRO) {
-    for (int c = tid; c < a.Kc; c += 256) { s_scale[c] = a.in_scale[c]; s_shift[c] = a.in_shift[c]; }
+  if constexpr (PRO != 0) {
+    for (int c = tid; c < a.Kc; c += 256) {
+      s_scale[c] = a.in_scale[c]; s_shift[c] = a.in_shift[c];
+      if constexpr (PRO == 2) s_gam[c] = a.pro_gam[c];
+    }
     __syncthreads();
   }
+  const long x2diff = (PRO == 2) ? (reinterpret_cast<const T*>(a.X2) - X) : 0;   // y sits at the same offsets as dz
   int tr = 0, ts = 0, c0 = 0;   // current tap (r, s) and channel offset of the K-chunk
   // Register ring of PD K-chunks: HBM/L2 latency (~2k cycles under load) is several chunks of MFMA work,
   // so loads run PD-1 chunks ahead of the LDS write that consumes them.
   constexpr int PD = 3;
   uint4 ra[PD][ALD], rb[PD][BLD];
+  uint4 ra2[PRO == 2 ? PD : 1][ALD];   // second gathered tensor (PRO == 2)
   int rc0[PD];                  // channel offset each ring slot was loaded at (for the BN prologue)
   unsigned rmask[PD];           // which of the slot's A rows were in bounds (padding stays exactly 0)
   const T* aptr[ALD];           // gathered pixel of the CURRENT tap (channel 0) per staged row
@@ -221,6 +267,7 @@ __global__ __launch_bounds__(256, 2) void k_igemm(ConvArgs a) {   // 2 waves/SIM
     for (int i = 0; i < ALD; ++i) {
       // UNCONDITIONAL load (a predicated one makes hipcc branch around it and wait vmcnt(0) per chunk)
       ra[slot][i] = *reinterpret_cast<const uint4*>(aptr[i] + c0);
+      if constexpr (PRO == 2) ra2[slot][i] = *reinterpret_cast<const uint4*>(aptr[i] + c0 + x2diff);
       m |= (aok[i] ? 1u : 0u) << i;
     }
     rmask[slot] = m;
@@ -244,8 +291,11 @@ __global__ __launch_bounds__(256, 2) void k_igemm(ConvArgs a) {   // 2 waves/SIM
 #pragma unroll
     for (int i = 0; i < ALD; ++i) {
       uint4 v = ra[slot][i];
-      if constexpr (PRO)
+      if constexpr (PRO == 1)
         v = bn_relu_vec<T>(v, s_scale + rc0[slot] + chunk * VEC, s_shift + rc0[slot] + chunk * VEC, a.in_relu);
+      if constexpr (PRO == 2)
+        v = affine2_vec<T>(v, ra2[slot][i], s_scale + rc0[slot] + chunk * VEC, s_shift + rc0[slot] + chunk * VEC,
+                           s_gam + rc0[slot] + chunk * VEC);
       if (!((rmask[slot] >> i) & 1u)) v = make_uint4(0, 0, 0, 0);      // padding is exactly zero AFTER the prologue
       const int row = srow + 64 * i;
       *reinterpret_cast<uint4*>(As + (row * 4 + (chunk ^ swz64(row))) * 16) = v;
@@ -363,6 +413,21 @@ __global__ __launch_bounds__(256, 2) void k_igemm(ConvArgs a) {   // 2 waves/SIM
       const float4 b0 = *reinterpret_cast<const float4*>(a.bias + nb), b1 = *reinterpret_cast<const float4*>(a.bias + nb + 4);
       bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w; bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
     }
+    // BN-backward epilogue constants of this lane's 8 channels
+    float emu[8], eis[8], esc[8], esh[8];
+    if (a.epi_bnbwd && nok) {
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const float4 x = *reinterpret_cast<const float4*>(a.e_mean + nb + 4 * q), y = *reinterpret_cast<const float4*>(a.e_invstd + nb + 4 * q);
+        emu[4 * q] = x.x; emu[4 * q + 1] = x.y; emu[4 * q + 2] = x.z; emu[4 * q + 3] = x.w;
+        eis[4 * q] = y.x; eis[4 * q + 1] = y.y; eis[4 * q + 2] = y.z; eis[4 * q + 3] = y.w;
+        if (a.e_out == nullptr) {
+          const float4 z = *reinterpret_cast<const float4*>(a.e_scale + nb + 4 * q), w = *reinterpret_cast<const float4*>(a.e_shift + nb + 4 * q);
+          esc[4 * q] = z.x; esc[4 * q + 1] = z.y; esc[4 * q + 2] = z.z; esc[4 * q + 3] = z.w;
+          esh[4 * q] = w.x; esh[4 * q + 1] = w.y; esh[4 * q + 2] = w.z; esh[4 * q + 3] = w.w;
+        }
+      }
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const int m = m0 + wm * WTM + i * 16 + fr;
@@ -371,38 +436,70 @@ __global__ __launch_bounds__(256, 2) void k_igemm(ConvArgs a) {   // 2 waves/SIM
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * a2 + (e >> 2)][e & 3] + bias[e];
         const long o = (long)m * a.Ncol + nb;
-        if (a.out_f32) {
-          if (a.addend) {
+        float yv[8];            // epi_bnbwd: raw conv output of the BN layer being back-propagated
+        bool on[8];
+        if (a.addend) {
+          if (a.out_f32 || sizeof(T) == 4) {
             const float4 p0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.addend) + o);
             const float4 p1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.addend) + o + 4);
             v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w; v[4] += p1.x; v[5] += p1.y; v[6] += p1.z; v[7] += p1.w;
-          }
-          float* yo = reinterpret_cast<float*>(a.Y) + o;
-          *reinterpret_cast<float4*>(yo) = make_float4(v[0], v[1], v[2], v[3]);
-          *reinterpret_cast<float4*>(yo + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        } else if constexpr (sizeof(T) == 4) {
-          if (a.addend) {
-            const float4 p0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.addend) + o);
-            const float4 p1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.addend) + o + 4);
-            v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w; v[4] += p1.x; v[5] += p1.y; v[6] += p1.z; v[7] += p1.w;
-          }
-          float* yo = reinterpret_cast<float*>(a.Y) + o;
-          *reinterpret_cast<float4*>(yo) = make_float4(v[0], v[1], v[2], v[3]);
-          *reinterpret_cast<float4*>(yo + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        } else {
-          if (a.addend) {
+          } else {
             const uint4 praw = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.addend) + o);
             const bf16x8 p = *reinterpret_cast<const bf16x8*>(&praw);
 #pragma unroll
             for (int e = 0; e < 8; ++e) v[e] += (float)p[e];
           }
+        }
+        if (a.epi_bnbwd) {
+          if constexpr (sizeof(T) == 4) {
+            const float4 y0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.e_y) + o);
+            const float4 y1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.e_y) + o + 4);
+            yv[0] = y0.x; yv[1] = y0.y; yv[2] = y0.z; yv[3] = y0.w; yv[4] = y1.x; yv[5] = y1.y; yv[6] = y1.z; yv[7] = y1.w;
+            if (a.e_out) {
+              const float4 o0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.e_out) + o);
+              const float4 o1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.e_out) + o + 4);
+              on[0] = o0.x > 0.f; on[1] = o0.y > 0.f; on[2] = o0.z > 0.f; on[3] = o0.w > 0.f;
+              on[4] = o1.x > 0.f; on[5] = o1.y > 0.f; on[6] = o1.z > 0.f; on[7] = o1.w > 0.f;
+            }
+          } else {
+            const uint4 yr = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.e_y) + o);
+            const bf16x8 yb = *reinterpret_cast<const bf16x8*>(&yr);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) yv[e] = (float)yb[e];
+            if (a.e_out) {
+              const uint4 orr = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.e_out) + o);
+              const bf16x8 ob = *reinterpret_cast<const bf16x8*>(&orr);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) on[e] = (float)ob[e] > 0.f;
+            }
+          }
+          if (!a.e_out) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) on[e] = fmaf(yv[e], esc[e], esh[e]) > 0.f;
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = on[e] ? v[e] : 0.f;
+        }
+        if (a.out_f32 || sizeof(T) == 4) {
+          float* yo = reinterpret_cast<float*>(a.Y) + o;
+          *reinterpret_cast<float4*>(yo) = make_float4(v[0], v[1], v[2], v[3]);
+          *reinterpret_cast<float4*>(yo + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
           bf16x8 t;
 #pragma unroll
           for (int e = 0; e < 8; ++e) { t[e] = (bf16_t)v[e]; v[e] = (float)t[e]; }   // stats of what the next layer reads
           *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.Y) + o) = *reinterpret_cast<uint4*>(&t);
         }
+        if (a.epi_bnbwd) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { csum[2 * a2 + (e >> 2)][e & 3] += v[e]; csq[2 * a2 + (e >> 2)][e & 3] += v[e] * v[e]; }
+          for (int e = 0; e < 8; ++e) {
+            csum[2 * a2 + (e >> 2)][e & 3] += v[e];
+            csq[2 * a2 + (e >> 2)][e & 3] += v[e] * (yv[e] - emu[e]) * eis[e];
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) { csum[2 * a2 + (e >> 2)][e & 3] += v[e]; csq[2 * a2 + (e >> 2)][e & 3] += v[e] * v[e]; }
+        }
       }
     }
   }
@@ -450,6 +547,8 @@ struct WgradArgs {
   const float* in_scale;  // prologue on X, as in forward
   const float* in_shift;
   int in_relu;
+  const void* dY2;        // YPRO: dY = alpha*dz + beta*y + gam  with dz = dY argument, y = dY2 (same indexing)
+  const float* y_coef;    // YPRO: [3][Co] (alpha, beta, gam) from frx_bn_bwd_finalize
   int N, Hx, Wx, Ci, Ho, Wo, Co, R, S, stride, pad, M;
   int stem;
   int tilesCo, tilesCi;
@@ -469,7 +568,7 @@ enum { WG_POINTWISE = 0, WG_GENERAL = 1, WG_STEM = 2 };
 // WMODE: gather geometry of the X operand (compile-time: keeps the K loop straight-line so the
 // register ring gets counted vmcnt waits).  PRO: BN+ReLU prologue on X; a thread's channel group
 // is the same for every chunk, so its 8 scale / 8 shift values stay in registers.
-template <typename T, int BT, int WMODE, bool PRO>   // BT x BT output tile (co x ci)
+template <typename T, int BT, int WMODE, bool PRO, bool YPRO>   // BT x BT output tile (co x ci)
 __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
   constexpr int VEC = TT<T>::VEC;
   constexpr int KP = (sizeof(T) == 2) ? 32 : 16;   // pixels per K-chunk
@@ -517,7 +616,18 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
     for (int j = 0; j < VEC; ++j) { psc[j] = ciok ? a.in_scale[ci + j] : 0.f; psh[j] = ciok ? a.in_shift[ci + j] : 0.f; }
   }
 
+  float yal[VEC], ybe[VEC], yga[VEC];          // YPRO: BN-backward coefficients of this thread's output channels
+  if constexpr (YPRO) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      yal[j] = cook ? a.y_coef[co + j] : 0.f;
+      ybe[j] = cook ? a.y_coef[a.Co + co + j] : 0.f;
+      yga[j] = cook ? a.y_coef[2 * a.Co + co + j] : 0.f;
+    }
+  }
+  const long y2diff = YPRO ? (reinterpret_cast<const T*>(a.dY2) - dY) : 0;
   uint4 ry[PD][LD], rx[PD][LD];
+  uint4 ry2[YPRO ? PD : 1][LD];
   unsigned rmask[PD];     // bit i: dY row valid, bit 8+i: X row valid (zero-filled at commit otherwise)
 
   auto issue_chunk = [&](int kc, auto slot_tag) {
@@ -529,6 +639,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
       const bool mok = m < a.M;
       const int mc = mok ? m : 0;
       ry[slot][i] = *reinterpret_cast<const uint4*>(ycol + (long)mc * a.Co);       // unconditional (clamped) loads
+      if constexpr (YPRO) ry2[slot][i] = *reinterpret_cast<const uint4*>(ycol + (long)mc * a.Co + y2diff);
       long xoff;
       bool xok = mok && ciok;
       if constexpr (WMODE == WG_POINTWISE) {
@@ -565,6 +676,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
       const int off = row * RB + ((ch * 16) ^ (sizeof(T) == 2 ? tr_swz<RB>(row) : 0));
       uint4 vy = ry[slot][i], vx = rx[slot][i];
       if constexpr (PRO) vx = bn_relu_vec<T>(vx, psc, psh, a.in_relu);
+      if constexpr (YPRO) vy = affine2_vec<T>(vy, ry2[slot][i], yal, ybe, yga);
       if (!((rmask[slot] >> i) & 1u)) vy = make_uint4(0, 0, 0, 0);
       if (!((rmask[slot] >> (8 + i)) & 1u)) vx = make_uint4(0, 0, 0, 0);
       *reinterpret_cast<uint4*>(Ys + off) = vy;

@@ -24,6 +24,11 @@ class ConvDesc(C.Structure):
                                           "Ho", "Wo", "stem")]
 
 
+class DgradFuse(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("pro_y", "pro_coef", "epi_y", "epi_out", "epi_scale", "epi_shift",
+                                          "epi_mean", "epi_invstd", "epi_partial")]
+
+
 def library_path() -> str:
     return _LIB_PATH
 
@@ -46,6 +51,9 @@ _SIGS = {
     "frx_conv_fwd": (C.c_int, [C.c_int, _P, C.POINTER(ConvDesc), _P, _P, _P, _P, C.c_int, _P, _P, C.c_int, _P]),
     "frx_conv_dgrad": (C.c_int, [C.c_int, _P, C.POINTER(ConvDesc), _P, _P, _P, _P]),
     "frx_conv_wgrad": (C.c_int, [C.c_int, _P, C.POINTER(ConvDesc), _P, _P, _P, C.c_int, _P, _P]),
+    "frx_conv_dgrad_stat_rows": (C.c_int, [C.POINTER(ConvDesc)]),
+    "frx_conv_dgrad_bn": (C.c_int, [C.c_int, _P, C.POINTER(ConvDesc), _P, _P, _P, _P, C.POINTER(DgradFuse)]),
+    "frx_conv_wgrad_bn": (C.c_int, [C.c_int, _P, C.POINTER(ConvDesc), _P, _P, _P, C.c_int, _P, _P, _P, _P]),
     "frx_bn_finalize": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int64, _P, _P, C.c_float, C.c_float,
                                   _P, _P, _P, _P, _P, _P]),
     "frx_bn_eval_affine": (C.c_int, [C.c_int, _P, C.c_int, _P, _P, _P, _P, C.c_float, _P, _P]),
@@ -53,7 +61,7 @@ _SIGS = {
     "frx_bn_bwd_partial_rows": (C.c_int, [C.c_int64, C.c_int]),
     "frx_bn_bwd_reduce": (C.c_int, [C.c_int, _P, C.c_int, C.c_int64, C.c_int, _P, _P, _P, _P, _P, C.c_int,
                                     _P, _P, _P, _P]),
-    "frx_bn_bwd_finalize": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int64, _P, _P, _P, _P, _P]),
+    "frx_bn_bwd_finalize": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int64, _P, _P, _P, _P, _P, _P]),
     "frx_bn_bwd_apply": (C.c_int, [C.c_int, _P, C.c_int, C.c_int64, C.c_int, _P, _P, _P, _P, _P, C.c_int,
                                    _P, _P, _P, _P]),
     "frx_stem_pool_fwd": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),

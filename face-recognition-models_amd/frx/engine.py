@@ -170,8 +170,10 @@ class ResNet50Engine:
         max_act = max(c.y.numel() for c in self.convs)
         self.scratch = [torch.empty(max_act, dtype=self.tdt, device=dev) for _ in range(5)]
         max_bp = max(ops.bn_bwd_partial_rows(c.y.numel() // c.Co, c.Co) * c.Co for c in self.convs)
+        max_bp = max([max_bp] + [ops.conv_dgrad_stat_rows(c.desc) * c.Ci for c in self.convs if not c.stem])
         self.bwd_partial = torch.empty(2 * max_bp, device=dev)
         self.coef = torch.empty(3 * 2048, device=dev)
+        self.coefs = [torch.empty(3 * 2048, device=dev) for _ in range(4)]     # bn3 / bn2 / bn1 / downsample in flight
         self.dfeat_t = torch.empty(N, FEATURE_DIM, dtype=self.tdt, device=dev)
         self.lr_dev = torch.zeros(1, device=dev)
         self.training = True
@@ -321,7 +323,7 @@ class ResNet50Engine:
         mean, invstd = self._bn(self.bn_mean, c), self._bn(self.bn_invstd, c)
         ops.bn_bwd_reduce(self.dtype, rows, c.Co, g, c.y, mean, invstd, self.bwd_partial, out=out, scale=sc, shift=sh,
                           relu=relu, dz_out=dz_out)
-        ops.bn_bwd_finalize(self.bwd_partial, nblk, c.Co, rows, self.gamma(c), invstd, self.gamma(c, self.grads),
+        ops.bn_bwd_finalize(self.bwd_partial, nblk, c.Co, rows, self.gamma(c), mean, invstd, self.gamma(c, self.grads),
                             self.beta(c, self.grads), self.coef)
         src = dz_out if dz_out is not None else g
         if dz_out is not None:
@@ -333,10 +335,33 @@ class ResNet50Engine:
     def _like(self, buf, ref):
         return buf[:ref.numel()].view(ref.shape)
 
+    def _finalize_bwd(self, c: ConvSpec, nrows_partial, coef):
+        """partial sums (sum dz, sum dz*xhat) -> dgamma/dbeta (+=) and the affine coefficients of dy"""
+        rows = c.y.numel() // c.Co
+        ops.bn_bwd_finalize(self.bwd_partial, nrows_partial, c.Co, rows, self.gamma(c), self._bn(self.bn_mean, c),
+                            self._bn(self.bn_invstd, c), self.gamma(c, self.grads), self.beta(c, self.grads), coef)
+
+    def _epi(self, c: ConvSpec, out=None):
+        """keyword arguments of conv_dgrad_bn's epilogue for back-propagating through BN `c` (+ ReLU / merge)"""
+        kw = dict(epi_y=c.y, epi_mean=self._bn(self.bn_mean, c), epi_invstd=self._bn(self.bn_invstd, c),
+                  epi_partial=self.bwd_partial)
+        if out is not None:
+            kw["epi_out"] = out
+        else:
+            kw["epi_scale"], kw["epi_shift"] = self._bn(self.bn_scale, c), self._bn(self.bn_shift, c)
+        return kw
+
     def backward(self, dfeat):
-        """dfeat [N,512] fp32: gradient of the loss w.r.t. feats.  Accumulates into self.grads."""
+        """dfeat [N,512] fp32: gradient of the loss w.r.t. feats.  Accumulates into self.grads.
+
+        BatchNorm backward is fused into the convolution backward wherever the conv is 1x1: the dgrad that
+        produces a gradient masks it and reduces sum(dz), sum(dz*xhat) in its epilogue, and the consumers
+        (dgrad / wgrad of the layer below) read dy = alpha*dz + beta*y + gam on the fly.  Only the 3x3 convs
+        (whose 9 taps would re-evaluate the prologue 9x), the downsample BNs and the stem keep the stand-alone
+        reduce / apply kernels."""
         N, dt = self.N, self.dtype
         S = self.scratch
+        C3, C2, C1, CD = self.coefs
         # fc
         ops.cast(dt, dfeat, self.dfeat_t, to_f32=False)
         ops.conv_wgrad(self.fc_desc, self.pooled, self.dfeat_t, self.fc_w(self.grads))
@@ -344,39 +369,56 @@ class ResNet50Engine:
         dpool = self._like(S[4], self.pooled)
         ops.conv_dgrad(self.fc_desc, self.dfeat_t, self.fc_wt, dpool)
         last = self.blocks[-1]
-        g = self._like(S[0], last.out)
+        g = self._like(S[3], last.out)
         ops.avgpool_bwd(dt, N, self.h_final * self.h_final, 2048, dpool, g)
-        gi = 0                                        # S[gi] holds g; S[1-gi] receives the next g
+        # last block: its output gradient comes from the pool, so mask + reduce run stand-alone
+        gi = 0
+        c3 = last.conv3
+        rows3 = c3.y.numel() // c3.Co
+        dz3 = self._like(S[gi], c3.y)
+        ops.bn_bwd_reduce(dt, rows3, c3.Co, g, c3.y, self._bn(self.bn_mean, c3), self._bn(self.bn_invstd, c3),
+                          self.bwd_partial, out=last.out, dz_out=dz3)
+        npart = ops.bn_bwd_partial_rows(rows3, c3.Co)
         for bi in range(len(self.blocks) - 1, -1, -1):
             b = self.blocks[bi]
-            x_in = self.blocks[bi - 1].out if bi > 0 else self.pool_out
+            prev = self.blocks[bi - 1] if bi > 0 else None
+            x_in = prev.out if prev is not None else self.pool_out
             c1, c2, c3, ds = b.conv1, b.conv2, b.conv3, b.down
-            dz = self._like(S[2], c3.y)               # g masked by the merge ReLU: feeds bn3 AND the identity
-            dy = self._like(S[3], c3.y)
-            self._bn_backward(c3, g, dy, out=b.out, dz_out=dz)
-            ops.conv_wgrad(c3.desc, c2.y, dy, self.w_grad(c3), in_scale=self._bn(self.bn_scale, c2),
-                           in_shift=self._bn(self.bn_shift, c2), in_relu=True)
-            dx3 = self._like(S[4], c2.y)
-            ops.conv_dgrad(c3.desc, dy, c3.wt, dx3)
+            dz3 = self._like(S[gi], c3.y)                         # masked block-output gradient (feeds bn3 AND the identity)
+            self._finalize_bwd(c3, npart, C3)
+            # conv3 (1x1): consumers read dy3 = affine(dz3, y3) on the fly; the dgrad epilogue handles bn2
+            ops.conv_wgrad_bn(c3.desc, c2.y, dz3, c3.y, C3, self.w_grad(c3), in_scale=self._bn(self.bn_scale, c2),
+                              in_shift=self._bn(self.bn_shift, c2), in_relu=True)
+            dz2 = self._like(S[4], c2.y)
+            ops.conv_dgrad_bn(c3.desc, dz3, c3.wt, dz2, pro_y=c3.y, pro_coef=C3, **self._epi(c2))
+            self._finalize_bwd(c2, ops.conv_dgrad_stat_rows(c3.desc), C2)
+            # conv2 (3x3): materialise dy2 once (9 taps would re-evaluate a prologue 9 times)
             dy2 = self._like(S[3], c2.y)
-            self._bn_backward(c2, dx3, dy2, relu=True)
+            rows2 = c2.y.numel() // c2.Co
+            ops.bn_bwd_apply(dt, rows2, c2.Co, dz2, c2.y, self._bn(self.bn_mean, c2), self._bn(self.bn_invstd, c2), C2, dy2)
             ops.conv_wgrad(c2.desc, c1.y, dy2, self.w_grad(c2), in_scale=self._bn(self.bn_scale, c1),
                            in_shift=self._bn(self.bn_shift, c1), in_relu=True)
-            dx2 = self._like(S[4], c1.y)
-            ops.conv_dgrad(c2.desc, dy2, c2.wt, dx2)
-            dy1 = self._like(S[3], c1.y)
-            self._bn_backward(c1, dx2, dy1, relu=True)
-            ops.conv_wgrad(c1.desc, x_in, dy1, self.w_grad(c1))
-            gnext = self._like(S[1 - gi], x_in)
+            dz1 = self._like(S[4], c1.y)
+            ops.conv_dgrad_bn(c2.desc, dy2, c2.wt, dz1, **self._epi(c1))
+            self._finalize_bwd(c1, ops.conv_dgrad_stat_rows(c2.desc), C1)
+            # conv1 (1x1)
+            ops.conv_wgrad_bn(c1.desc, x_in, dz1, c1.y, C1, self.w_grad(c1))
+            addend = dz3
             if ds is not None:
-                dyd = self._like(S[4], ds.y)
-                self._bn_backward(ds, dz, dyd)
-                ops.conv_wgrad(ds.desc, x_in, dyd, self.w_grad(ds))
-                tmp = self._like(S[gi], x_in)         # g itself is dead once dz exists
-                ops.conv_dgrad(ds.desc, dyd, ds.wt, tmp)
-                ops.conv_dgrad(c1.desc, dy1, c1.wt, gnext, addend=tmp)
+                rowsd = ds.y.numel() // ds.Co
+                ops.bn_bwd_reduce(dt, rowsd, ds.Co, dz3, ds.y, self._bn(self.bn_mean, ds), self._bn(self.bn_invstd, ds),
+                                  self.bwd_partial)
+                self._finalize_bwd(ds, ops.bn_bwd_partial_rows(rowsd, ds.Co), CD)
+                ops.conv_wgrad_bn(ds.desc, x_in, dz3, ds.y, CD, self.w_grad(ds))
+                addend = self._like(S[2], x_in)
+                ops.conv_dgrad_bn(ds.desc, dz3, ds.wt, addend, pro_y=ds.y, pro_coef=CD)
+            gnext = self._like(S[1 - gi], x_in)
+            if prev is not None:      # epilogue: merge-ReLU mask of the block below + its bn3 reduce
+                ops.conv_dgrad_bn(c1.desc, dz1, c1.wt, gnext, addend=addend, pro_y=c1.y, pro_coef=C1,
+                                  **self._epi(prev.conv3, out=prev.out))
+                npart = ops.conv_dgrad_stat_rows(c1.desc)
             else:
-                ops.conv_dgrad(c1.desc, dy1, c1.wt, gnext, addend=dz)
+                ops.conv_dgrad_bn(c1.desc, dz1, c1.wt, gnext, addend=addend, pro_y=c1.y, pro_coef=C1)
             g, gi = gnext, 1 - gi
         # stem: max-pool -> ReLU/BN -> conv weight gradient (no image gradient)
         s = self.stem

@@ -211,6 +211,34 @@ def conv_wgrad(d, x, dy, dw, in_scale=None, in_shift=None, in_relu=False):
     return dw
 
 
+def conv_dgrad_stat_rows(d):
+    r = _lib.lib().frx_conv_dgrad_stat_rows(C.byref(d))
+    if r < 0:
+        raise FrxError("conv descriptor rejected: " + _lib.lib().frx_last_error().decode())
+    return r
+
+
+def conv_dgrad_bn(d, dz, w_crsk, dx, addend=None, pro_y=None, pro_coef=None, epi_y=None, epi_out=None, epi_scale=None,
+                  epi_shift=None, epi_mean=None, epi_invstd=None, epi_partial=None):
+    """dgrad with the BatchNorm backward fused in (prologue: dy = alpha*dz + beta*pro_y + gam; epilogue: mask +
+    per-channel reduce of the produced gradient)."""
+    f = _lib.DgradFuse(*[0 if t is None else t.data_ptr() for t in
+                         (pro_y, pro_coef, epi_y, epi_out, epi_scale, epi_shift, epi_mean, epi_invstd, epi_partial)])
+    bm, bn = _igemm_tile(d.N * d.Hi * d.Wi, d.Ci)
+    _timed(f"k_igemm<{_dt_name(d.dtype)},{bm},{bn}>", conv_flops(d), dz, lambda: check(
+        _lib.lib().frx_conv_dgrad_bn(_dev(dz), _stream(dz), C.byref(d), _p(dz), _p(w_crsk), _p(addend), _p(dx),
+                                     C.byref(f)), "frx_conv_dgrad_bn"))
+    return dx
+
+
+def conv_wgrad_bn(d, x, dz, pro_y, pro_coef, dw, in_scale=None, in_shift=None, in_relu=False):
+    bt = 64 if (d.Co <= 64 or d.Ci <= 64) else 128
+    _timed(f"k_wgrad<{_dt_name(d.dtype)},{bt}>", conv_flops(d), x, lambda: check(
+        _lib.lib().frx_conv_wgrad_bn(_dev(x), _stream(x), C.byref(d), _p(x), _p(in_scale), _p(in_shift), int(in_relu),
+                                     _p(dz), _p(pro_y), _p(pro_coef), _p(dw)), "frx_conv_wgrad_bn"))
+    return dw
+
+
 def bn_finalize(partial, rows, Cc, count, gamma, beta, rmean, rvar, mean, invstd, scale, shift, eps=1e-5, momentum=0.1):
     check(_lib.lib().frx_bn_finalize(_dev(partial), _stream(partial), _p(partial), rows, Cc, count, _p(gamma), _p(beta),
                                      eps, momentum, _p(rmean), _p(rvar), _p(mean), _p(invstd), _p(scale), _p(shift)),
@@ -238,9 +266,9 @@ def bn_bwd_reduce(dtype, rows, Cc, g, y, mean, invstd, partial, out=None, scale=
           "frx_bn_bwd_reduce")
 
 
-def bn_bwd_finalize(partial, nblk, Cc, count, gamma, invstd, dgamma, dbeta, coef):
+def bn_bwd_finalize(partial, nblk, Cc, count, gamma, mean, invstd, dgamma, dbeta, coef):
     check(_lib.lib().frx_bn_bwd_finalize(_dev(partial), _stream(partial), _p(partial), nblk, Cc, count, _p(gamma),
-                                         _p(invstd), _p(dgamma), _p(dbeta), _p(coef)), "frx_bn_bwd_finalize")
+                                         _p(mean), _p(invstd), _p(dgamma), _p(dbeta), _p(coef)), "frx_bn_bwd_finalize")
 
 
 def bn_bwd_apply(dtype, rows, Cc, g, y, mean, invstd, coef, dy, out=None, scale=None, shift=None, relu=False):

@@ -137,6 +137,28 @@ int frx_conv_fwd(int device, frx_stream_t stream, const frx_conv_desc* d, const 
 /* dx = conv_transpose(dy, w) [+ addend]   (addend: the residual branch's gradient) */
 int frx_conv_dgrad(int device, frx_stream_t stream, const frx_conv_desc* d, const void* dy, const void* w_crsk,
                    const void* addend, void* dx);
+/* BatchNorm backward fused into the convolution backward (saves two HBM passes per layer):
+ *   prologue: the kernel reads  dy = alpha*dz + beta*pro_y + gam  on the fly (frx_bn_bwd_finalize's coef);
+ *   epilogue: the freshly computed input gradient g is masked (ReLU of the producing layer: out > 0, or
+ *             epi_scale*epi_y + epi_shift > 0), stored as dz, and  sum(dz), sum(dz*xhat)  per channel go to
+ *             epi_partial [frx_conv_dgrad_stat_rows][2][Ci]  (then frx_bn_bwd_finalize as usual). */
+typedef struct frx_dgrad_fuse {
+  const void* pro_y;         /* raw output y of THIS conv (dtype T, [N,Ho,Wo,Co]); NULL: `dz` argument already is dy */
+  const float* pro_coef;     /* [3][Co] */
+  const void* epi_y;         /* raw output of the conv that produced this conv's INPUT ([N,Hi,Wi,Ci]); NULL: no epilogue */
+  const void* epi_out;       /* optional block output for the merge-ReLU mask */
+  const float* epi_scale;    /* mask = epi_scale*epi_y + epi_shift > 0 when epi_out is NULL */
+  const float* epi_shift;
+  const float* epi_mean;
+  const float* epi_invstd;
+  float* epi_partial;
+} frx_dgrad_fuse;
+int frx_conv_dgrad_stat_rows(const frx_conv_desc* d);
+int frx_conv_dgrad_bn(int device, frx_stream_t stream, const frx_conv_desc* d, const void* dz, const void* w_crsk,
+                      const void* addend, void* dx, const frx_dgrad_fuse* fuse);
+int frx_conv_wgrad_bn(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x, const float* in_scale,
+                      const float* in_shift, int in_relu, const void* dz, const void* pro_y, const float* pro_coef,
+                      float* dw);
 /* dw (fp32 KRSC, accumulated) += f(x)^T dy */
 int frx_conv_wgrad(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x, const float* in_scale,
                    const float* in_shift, int in_relu, const void* dy, float* dw);
@@ -156,14 +178,17 @@ int frx_block_merge_fwd(int device, frx_stream_t stream, int dtype, int64_t rows
 /* BatchNorm backward in three steps.  dz = g*mask with mask = (out>0) if out given, else
  * (scale*y+shift>0) if relu, else 1.
  *   reduce   -> partial [frx_bn_bwd_partial_rows][2][C] = (sum dz, sum dz*xhat); optional dz_out
- *   finalize -> dgamma +=, dbeta +=, coef [3][C] = (gamma*invstd, sum dz / M, sum dz*xhat / M)
- *   apply    -> dy = coef0 * (dz - coef1 - xhat*coef2) */
+ *   finalize -> dgamma +=, dbeta +=, coef [3][C] = (alpha, beta, gam): the BN backward is AFFINE in (dz, y),
+ *               dy = alpha*dz + beta*y + gam  with alpha = gamma*invstd, beta = -alpha*invstd*mean(dz*xhat),
+ *               gam = alpha*(mu*invstd*mean(dz*xhat) - mean(dz))
+ *   apply    -> dy = alpha*dz + beta*y + gam   (or fused into the consumers: frx_conv_dgrad_bn / frx_conv_wgrad_bn) */
 int frx_bn_bwd_partial_rows(int64_t rows, int C);
 int frx_bn_bwd_reduce(int device, frx_stream_t stream, int dtype, int64_t rows, int C, const void* g, const void* y,
                       const void* out, const float* scale, const float* shift, int relu, const float* mean,
                       const float* invstd, void* dz_out, float* partial);
 int frx_bn_bwd_finalize(int device, frx_stream_t stream, const float* partial, int nblk, int C, int64_t count,
-                        const float* gamma, const float* invstd, float* dgamma, float* dbeta, float* coef);
+                        const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
+                        float* coef);
 int frx_bn_bwd_apply(int device, frx_stream_t stream, int dtype, int64_t rows, int C, const void* g, const void* y,
                      const void* out, const float* scale, const float* shift, int relu, const float* mean,
                      const float* invstd, const float* coef, void* dy);

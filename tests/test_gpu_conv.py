@@ -146,3 +146,59 @@ def test_fc_as_conv(dtype):
     dx = torch.empty(N, 16, 2048, dtype=x.dtype, device=DEV)
     ops.avgpool_bwd(dtype, N, 16, 2048, dpool.to(DEV), dx)
     _close(dx, (dpool.float() / 16)[:, None, :].expand(N, 16, 2048), dtype, "avgpool bwd")
+
+
+@pytest.mark.parametrize("dtype", [0, 1], ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(64, 256, 1, 1, 28), (256, 64, 1, 1, 28), (512, 128, 1, 1, 14), (256, 512, 1, 2, 28),
+                                   (128, 128, 3, 1, 14), (2048, 512, 1, 1, 4)],
+                         ids=lambda s: f"{s[0]}x{s[1]}k{s[2]}s{s[3]}h{s[4]}")
+@pytest.mark.parametrize("merge_mask", [False, True], ids=["relu_bn_mask", "merge_mask"])
+def test_fused_bn_backward_in_dgrad_wgrad(dtype, shape, merge_mask):
+    """frx_conv_dgrad_bn / frx_conv_wgrad_bn == (bn_bwd_apply -> dgrad -> bn_bwd_reduce) and (apply -> wgrad)."""
+    from frx import ops
+    Ci, Co, k, stride, Hi = shape
+    N, pad = 3, k // 2
+    d = ops.conv_desc(dtype, N, Hi, Hi, Ci, Co, k, k, stride, pad)
+    T = ops.TORCH_DT[dtype]
+    dz = _mk(dtype, N, d.Ho, d.Wo, Co, seed=1).to(DEV)           # masked upstream gradient of THIS conv's BN
+    y = _mk(dtype, N, d.Ho, d.Wo, Co, seed=2).to(DEV)            # this conv's raw output
+    g = torch.Generator().manual_seed(3)
+    coef = torch.cat([torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g) * 0.2, torch.randn(Co, generator=g) * 0.1]).to(DEV)
+    w = _mk(dtype, Co, k, k, Ci, scale=(Ci * k * k) ** -0.5, seed=4).to(DEV)
+    wt = w.permute(3, 1, 2, 0).contiguous()
+    x = _mk(dtype, N, Hi, Hi, Ci, seed=5).to(DEV)                # conv input activation (post-ReLU) / block input
+    add = _mk(dtype, N, Hi, Hi, Ci, seed=6).to(DEV)
+    # reference composition with the stand-alone kernels
+    dy = (coef[:Co] * dz.float() + coef[Co:2 * Co] * y.float() + coef[2 * Co:]).to(T)
+    dx_ref = torch.empty(N, Hi, Hi, Ci, dtype=T, device=DEV)
+    ops.conv_dgrad(d, dy, wt, dx_ref, addend=add)
+    # the layer that produced this conv's input: raw output ey, BN stats, (optionally) a merge output
+    ey = _mk(dtype, N, Hi, Hi, Ci, seed=7).to(DEV)
+    esc = (torch.rand(Ci, generator=g) + 0.5).to(DEV)
+    esc[::4] *= -1
+    esh = (torch.randn(Ci, generator=g) * 0.3).to(DEV)
+    emu, eis = (torch.randn(Ci, generator=g) * 0.2).to(DEV), (torch.rand(Ci, generator=g) + 0.5).to(DEV)
+    eout = torch.relu(_mk(dtype, N, Hi, Hi, Ci, seed=8)).to(DEV) if merge_mask else None
+    rows = N * Hi * Hi
+    nblk = ops.bn_bwd_partial_rows(rows, Ci)
+    part_ref = torch.zeros(nblk, 2, Ci, device=DEV)
+    dz_ref = torch.empty_like(dx_ref)
+    ops.bn_bwd_reduce(dtype, rows, Ci, dx_ref, ey, emu, eis, part_ref, out=eout, scale=esc, shift=esh, relu=True, dz_out=dz_ref)
+    # fused
+    prow = ops.conv_dgrad_stat_rows(d)
+    part = torch.zeros(prow, 2, Ci, device=DEV)
+    dz_out = torch.empty_like(dx_ref)
+    ops.conv_dgrad_bn(d, dz, wt, dz_out, addend=add, pro_y=y, pro_coef=coef, epi_y=ey, epi_out=eout, epi_scale=esc,
+                      epi_shift=esh, epi_mean=emu, epi_invstd=eis, epi_partial=part)
+    _close(dz_out, dz_ref.float().cpu(), dtype, "fused dz")
+    s_ref, s = part_ref.sum(0).cpu(), part.sum(0).cpu()
+    scale = s_ref.abs().max().item() + 1e-6
+    assert (s - s_ref).abs().max().item() < (2e-3 if dtype == 0 else 3e-2) * scale
+    # fused wgrad
+    sc = (torch.rand(Ci, generator=g) + 0.5).to(DEV)
+    sh = (torch.randn(Ci, generator=g) * 0.3).to(DEV)
+    dw_ref = torch.zeros(Co, k, k, Ci, device=DEV)
+    ops.conv_wgrad(d, x, dy, dw_ref, in_scale=sc, in_shift=sh, in_relu=True)
+    dw = torch.zeros_like(dw_ref)
+    ops.conv_wgrad_bn(d, x, dz, y, coef, dw, in_scale=sc, in_shift=sh, in_relu=True)
+    _close(dw, dw_ref.cpu(), dtype, "fused wgrad")
