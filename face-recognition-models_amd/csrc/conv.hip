@@ -18,6 +18,13 @@ static TileCfg pick_tile(long M, int Ncol) {
 template <typename T>
 static int launch_igemm(hipStream_t st, ConvArgs a) {
   FRX_CHECK_ARG(a.Ncol % 8 == 0, "igemm: output channel count %d must be a multiple of 8", a.Ncol);
+  {
+    const size_t esz = sizeof(T);
+    const size_t xb = (size_t)a.N * a.Hx * a.Wx * (a.mode == MODE_STEM ? 4 : a.Kc) * esz;
+    const size_t wb = (size_t)a.Ncol * (a.mode == MODE_STEM ? a.R * 32 : a.R * a.S * a.Kc) * esz;
+    FRX_CHECK_ARG(xb < 0x80000000ull && wb < 0x80000000ull, "igemm: tensors must stay below 2 GiB (32-bit buffer offsets)");
+    a.xbytes = (unsigned)xb; a.wbytes = (unsigned)wb;
+  }
   const TileCfg c = pick_tile(a.M, a.Ncol);
   a.tilesM = cdiv(a.M, c.bm);
   a.tilesN = cdiv(a.Ncol, c.bn);

@@ -50,7 +50,11 @@ struct ConvArgs {
   int M;
   int mode;
   int tilesM, tilesN;
+  unsigned xbytes, wbytes;   // sizes of X (and X2) and W in bytes: buffer-load bounds (out-of-range reads return 0)
 };
+
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 as_uint4(u32x4_t v) { return make_uint4(v[0], v[1], v[2], v[3]); }
 
 // ds_read_b128 of a [rows][64 B] image is 2-way bank-conflicted for the 16x16x32 fragment
 // pattern (row = lane&15, chunk = lane>>4); XOR-ing the 16-byte chunk index with h[(row>>2)&3],
@@ -203,13 +207,18 @@ __global__ __launch_bounds__(256, 2) void k_igemm(ConvArgs a) {   // 2 waves/SIM
     else if (MODE == MODE_DGRAD) { rh[i] = oh + a.pad; rw[i] = ow + a.pad; }
     else { rh[i] = oh * 2; rw[i] = ow * 2; }
   }
-  const T* bptr[BLD];
-  bool bok[BLD];
+  // All tile loads are buffer loads: a 32-bit per-lane byte offset (fixed per tap) plus a SCALAR offset
+  // that walks the contraction axis, so the K loop spends no vector ALU on addresses, and an offset past
+  // the end of the tensor returns zeros (padding taps and tile tails need no select).
+  const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.X), 0, a.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcX2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(PRO == 2 ? a.X2 : a.X), 0, a.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, a.wbytes, 0x00020000);
+  constexpr unsigned OOB = 0x80000000u;
+  unsigned bvoff[BLD];
 #pragma unroll
   for (int i = 0; i < BLD; ++i) {
-    const int n = n0 + srow + 64 * i;
-    bok[i] = n < a.Ncol;
-    bptr[i] = Wp + (long)(bok[i] ? n : 0) * ldw + chunk * VEC;
+    const int n = n0 + srow + 64 * i;                 // rows past Ncol read zeros; their outputs are never stored
+    bvoff[i] = n < a.Ncol ? (unsigned)((n * ldw + chunk * VEC) * (int)sizeof(T)) : OOB;
   }
 
   if constexpr (PRO != 0) {
@@ -219,7 +228,7 @@ __global__ __launch_bounds__(256, 2) void k_igemm(ConvArgs a) {   // 2 waves/SIM
     }
     __syncthreads();
   }
-  const long x2diff = (PRO == 2) ? (reinterpret_cast<const T*>(a.X2) - X) : 0;   // y sits at the same offsets as dz
+
   int tr = 0, ts = 0, c0 = 0;   // current tap (r, s) and channel offset of the K-chunk
   // Register ring of PD K-chunks: HBM/L2 latency (~2k cycles under load) is several chunks of MFMA work,
   // so loads run PD-1 chunks ahead of the LDS write that consumes them.
@@ -228,7 +237,7 @@ __global__ __launch_bounds__(256, 2) void k_igemm(ConvArgs a) {   // 2 waves/SIM
   uint4 ra2[PRO == 2 ? PD : 1][ALD];   // second gathered tensor (PRO == 2)
   int rc0[PD];                  // channel offset each ring slot was loaded at (for the BN prologue)
   unsigned rmask[PD];           // which of the slot's A rows were in bounds (padding stays exactly 0)
-  const T* aptr[ALD];           // gathered pixel of the CURRENT tap (channel 0) per staged row
+  unsigned avoff[ALD];          // byte offset of the gathered pixel of the CURRENT tap (OOB when out of bounds)
   bool aok[ALD];
 
   // Address arithmetic and bounds checks run once per tap, not once per K-chunk: inside a tap the
@@ -237,23 +246,23 @@ __global__ __launch_bounds__(256, 2) void k_igemm(ConvArgs a) {   // 2 waves/SIM
 #pragma unroll
     for (int i = 0; i < ALD; ++i) {
       bool ok = rok[i];
-      long off;
+      int off;
       if (MODE == MODE_FWD) {
         const int hi = rh[i] + tr, wi = rw[i] + ts;
         ok = ok && (unsigned)hi < (unsigned)a.Hx && (unsigned)wi < (unsigned)a.Wx;
-        off = (((long)rn[i] * a.Hx + hi) * a.Wx + wi) * a.Kc;
+        off = ((rn[i] * a.Hx + hi) * a.Wx + wi) * a.Kc;
       } else if (MODE == MODE_DGRAD) {
         const int th = rh[i] - tr, tw = rw[i] - ts;
         const int sm = a.stride - 1, sh = a.stride >> 1;   // stride is 1 or 2
         ok = ok && th >= 0 && tw >= 0 && ((th & sm) == 0) && ((tw & sm) == 0);
         const int hi = th >> sh, wi = tw >> sh;
         ok = ok && hi < a.Hx && wi < a.Wx;
-        off = (((long)rn[i] * a.Hx + hi) * a.Wx + wi) * a.Kc;
+        off = ((rn[i] * a.Hx + hi) * a.Wx + wi) * a.Kc;
       } else {  // stem: physically padded NHWC4 input, row tr, 8 taps x 4 channels = 32 elements
-        off = (((long)rn[i] * a.Hx + rh[i] + tr) * a.Wx + rw[i]) * 4;
+        off = ((rn[i] * a.Hx + rh[i] + tr) * a.Wx + rw[i]) * 4;
       }
       aok[i] = ok;
-      aptr[i] = X + (ok ? off : 0) + chunk * VEC;   // out-of-bounds rows read pixel 0 and are zeroed at commit
+      avoff[i] = ok ? (unsigned)((off + chunk * VEC) * (int)sizeof(T)) : OOB;
     }
   };
   set_tap();
@@ -262,18 +271,18 @@ __global__ __launch_bounds__(256, 2) void k_igemm(ConvArgs a) {   // 2 waves/SIM
   auto issue_chunk = [&](int kc, auto slot_tag) {
     constexpr int slot = decltype(slot_tag)::value;
     rc0[slot] = c0;
+    const int so = c0 * (int)sizeof(T);             // scalar offsets: wave-uniform
     unsigned m = 0;
 #pragma unroll
     for (int i = 0; i < ALD; ++i) {
-      // UNCONDITIONAL load (a predicated one makes hipcc branch around it and wait vmcnt(0) per chunk)
-      ra[slot][i] = *reinterpret_cast<const uint4*>(aptr[i] + c0);
-      if constexpr (PRO == 2) ra2[slot][i] = *reinterpret_cast<const uint4*>(aptr[i] + c0 + x2diff);
+      ra[slot][i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rsrcX, avoff[i], so, 0));
+      if constexpr (PRO == 2) ra2[slot][i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rsrcX2, avoff[i], so, 0));
       m |= (aok[i] ? 1u : 0u) << i;
     }
     rmask[slot] = m;
+    const int sob = kc * 64;
 #pragma unroll
-    for (int i = 0; i < BLD; ++i)
-      rb[slot][i] = *reinterpret_cast<const uint4*>(bptr[i] + (long)kc * CE);
+    for (int i = 0; i < BLD; ++i) rb[slot][i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rsrcW, bvoff[i], sob, 0));
     // advance the tap walker to chunk kc+1
     c0 += CE;
     const int span = (MODE == MODE_STEM) ? 32 : a.Kc;
@@ -296,14 +305,16 @@ __global__ __launch_bounds__(256, 2) void k_igemm(ConvArgs a) {   // 2 waves/SIM
       if constexpr (PRO == 2)
         v = affine2_vec<T>(v, ra2[slot][i], s_scale + rc0[slot] + chunk * VEC, s_shift + rc0[slot] + chunk * VEC,
                            s_gam + rc0[slot] + chunk * VEC);
-      if (!((rmask[slot] >> i) & 1u)) v = make_uint4(0, 0, 0, 0);      // padding is exactly zero AFTER the prologue
+      if constexpr (PRO != 0) {      // out-of-range loads are already 0; a prologue would turn them into f(0)
+        if (!((rmask[slot] >> i) & 1u)) v = make_uint4(0, 0, 0, 0);
+      }
       const int row = srow + 64 * i;
       *reinterpret_cast<uint4*>(As + (row * 4 + (chunk ^ swz64(row))) * 16) = v;
     }
 #pragma unroll
     for (int i = 0; i < BLD; ++i) {
       const int row = srow + 64 * i;
-      *reinterpret_cast<uint4*>(Bs + (row * 4 + (chunk ^ swz64(row))) * 16) = bok[i] ? rb[slot][i] : make_uint4(0, 0, 0, 0);
+      *reinterpret_cast<uint4*>(Bs + (row * 4 + (chunk ^ swz64(row))) * 16) = rb[slot][i];
     }
   };
 

@@ -15,7 +15,7 @@ def timed(label, flops, t, fn):
     calls.append(label); return orig(label, flops, t, fn)
 ops._timed = timed
 descs = []
-for name in ("conv_fwd", "conv_dgrad", "conv_wgrad"):
+for name in ("conv_fwd", "conv_dgrad", "conv_wgrad", "conv_dgrad_bn", "conv_wgrad_bn"):
     f = getattr(ops, name)
     def mk(f, name):
         def w(d, *a, **k):
