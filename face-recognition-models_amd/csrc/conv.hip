@@ -2,49 +2,34 @@
 // Reference call sites replaced: every nn.Conv2d / nn.Linear of the torchvision ResNet-50 the
 // reference builds in main_code/utils/backbones.py:16-18, forward and autograd backward
 // (main_code/utils/criterion.py:320, model_utils.py:177,185).
-#include "conv_kernels.h"
+#include "conv_launch.h"
 
 namespace frx {
 
-struct TileCfg { int bm, bn; };
-
-static TileCfg pick_tile(long M, int Ncol) {
-  if (Ncol <= 64) return {128, 64};
-  const long tiles128 = ((M + 127) / 128) * ((Ncol + 127) / 128);
-  if (tiles128 < 384) return {64, 64};     // small problems: fill the 256 CUs
-  return {128, 128};
-}
-
-template <typename T>
-static int launch_igemm(hipStream_t st, ConvArgs a) {
-  FRX_CHECK_ARG(a.Ncol % 8 == 0, "igemm: output channel count %d must be a multiple of 8", a.Ncol);
-  {
-    const size_t esz = sizeof(T);
-    const size_t xb = (size_t)a.N * a.Hx * a.Wx * (a.mode == MODE_STEM ? 4 : a.Kc) * esz;
-    const size_t wb = (size_t)a.Ncol * (a.mode == MODE_STEM ? a.R * 32 : a.R * a.S * a.Kc) * esz;
-    FRX_CHECK_ARG(xb < 0x80000000ull && wb < 0x80000000ull, "igemm: tensors must stay below 2 GiB (32-bit buffer offsets)");
-    a.xbytes = (unsigned)xb; a.wbytes = (unsigned)wb;
-  }
-  const TileCfg c = pick_tile(a.M, a.Ncol);
+static int launch_igemm(hipStream_t st, ConvArgs a, int dtype) {
+  FRX_CHECK_ARG(a.Ncol % 64 == 0, "igemm: output channel count %d must be a multiple of 64", a.Ncol);
+  const size_t esz = dtype == FRX_BF16 ? 2 : 4;
+  const size_t xb = (size_t)a.N * a.Hx * a.Wx * (a.mode == MODE_STEM ? 4 : a.Kc) * esz;
+  const size_t wb = (size_t)a.Ncol * (a.mode == MODE_STEM ? a.R * 32 : a.R * a.S * a.Kc) * esz;
+  const size_t yb = (size_t)a.M * a.Ncol * 4;
+  FRX_CHECK_ARG(xb < 0x80000000ull && wb < 0x80000000ull && yb < 0x80000000ull,
+                "igemm: tensors must stay below 2 GiB (32-bit buffer offsets)");
+  a.xbytes = (unsigned)xb; a.wbytes = (unsigned)wb;
+  TileCfg c = pick_tile(a.M, a.Ncol);
+  if (a.Ncol % c.bn != 0) c = TileCfg{c.bm, 64};
   a.tilesM = cdiv(a.M, c.bm);
   a.tilesN = cdiv(a.Ncol, c.bn);
   const int grid = (int)round_up(a.tilesM, 8) * a.tilesN;
-#define FRX_IGEMM(BM_, BN_, MODE_, PRO_) \
-  hipLaunchKernelGGL((k_igemm<T, BM_, BN_, 2, 2, MODE_, PRO_>), dim3(grid), dim3(256), 0, st, a)
-#define FRX_IGEMM_TILE(MODE_, PRO_)                                   \
-  do {                                                                \
-    if (c.bm == 128 && c.bn == 128) FRX_IGEMM(128, 128, MODE_, PRO_); \
-    else if (c.bm == 128 && c.bn == 64) FRX_IGEMM(128, 64, MODE_, PRO_); \
-    else FRX_IGEMM(64, 64, MODE_, PRO_);                              \
-  } while (0)
-  if (a.mode == MODE_STEM) FRX_IGEMM_TILE(MODE_STEM, 0);
-  else if (a.mode == MODE_DGRAD) { if (a.X2) FRX_IGEMM_TILE(MODE_DGRAD, 2); else FRX_IGEMM_TILE(MODE_DGRAD, 0); }
-  else if (a.in_scale) FRX_IGEMM_TILE(MODE_FWD, 1);
-  else FRX_IGEMM_TILE(MODE_FWD, 0);
-#undef FRX_IGEMM_TILE
-#undef FRX_IGEMM
-  FRX_LAUNCH_CHECK();
-  return FRX_OK;
+  int epi = EPI_PLAIN;
+  if (a.epi_bnbwd) epi = a.e_out ? EPI_BNBWD_OUT : EPI_BNBWD;
+  else if (a.stat_partial) epi = EPI_STATS;
+  else if (a.out_f32 || a.bias) epi = EPI_FC;
+  if (a.mode == MODE_STEM) return launch_igemm_stem(st, a, dtype, c, grid, epi);
+  if (a.mode == MODE_DGRAD)
+    return a.X2 ? launch_igemm_dgrad_bn(st, a, dtype, c, grid, epi, a.addend != nullptr)
+                : launch_igemm_dgrad_plain(st, a, dtype, c, grid, epi, a.addend != nullptr);
+  FRX_CHECK_ARG(a.addend == nullptr, "igemm fwd: addend is a dgrad feature");
+  return launch_igemm_fwd(st, a, dtype, c, grid, a.in_scale ? 1 : 0, epi);
 }
 
 static int check_conv(const frx_conv_desc* d) {
@@ -95,6 +80,8 @@ extern "C" int frx_conv_fwd(int device, frx_stream_t stream, const frx_conv_desc
   FRX_CHECK_ARG(x && w && y, "conv_fwd: NULL pointer");
   FRX_CHECK_ARG(!(d->stem && in_scale), "conv_fwd: the stem takes the raw image (no prologue)");
   FRX_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "conv_fwd: in_scale/in_shift must come together");
+  FRX_CHECK_ARG((bias != nullptr) == (out_f32 != 0), "conv_fwd: bias and fp32 output come together (the fc layer)");
+  FRX_CHECK_ARG(!(bias && (stat_partial || in_scale)), "conv_fwd: the fc flavour takes no prologue / statistics");
   FRX_CHECK_ARG(!in_scale || d->Ci <= 2048, "conv_fwd: BN prologue supports up to 2048 input channels (got %d)", d->Ci);
   FRX_ENTER(device);
   ConvArgs a{};
@@ -111,7 +98,7 @@ extern "C" int frx_conv_fwd(int device, frx_stream_t stream, const frx_conv_desc
   } else {
     a.mode = MODE_FWD; a.Hx = d->Hi; a.Wx = d->Wi; a.Kc = d->Ci;
   }
-  return d->dtype == FRX_BF16 ? launch_igemm<bf16_t>((hipStream_t)stream, a) : launch_igemm<float>((hipStream_t)stream, a);
+  return launch_igemm((hipStream_t)stream, a, d->dtype);
 }
 
 static int dgrad_impl(int device, frx_stream_t stream, const frx_conv_desc* d, const void* dy, const void* w_crsk,
@@ -140,7 +127,7 @@ static int dgrad_impl(int device, frx_stream_t stream, const frx_conv_desc* d, c
     }
   }
   FRX_ENTER(device);
-  return d->dtype == FRX_BF16 ? launch_igemm<bf16_t>((hipStream_t)stream, a) : launch_igemm<float>((hipStream_t)stream, a);
+  return launch_igemm((hipStream_t)stream, a, d->dtype);
 }
 
 extern "C" int frx_conv_dgrad(int device, frx_stream_t stream, const frx_conv_desc* d, const void* dy,
@@ -198,30 +185,8 @@ static int wgrad_impl(int device, frx_stream_t stream, const frx_conv_desc* d, c
   splits = cdiv(nchunks, a.chunks_per_split);
   a.splits = splits;
   dim3 grid(a.tilesCo * a.tilesCi * taps * splits), block(256);
-  hipStream_t st = (hipStream_t)stream;
   const int wmode = d->stem ? WG_STEM : ((d->R == 1 && d->S == 1 && d->stride == 1) ? WG_POINTWISE : WG_GENERAL);
-  const bool pro = in_scale != nullptr;
-  const bool ypro = pro_y != nullptr;
-#define FRX_WG(T_, BT_, WM_, PRO_)                                                                    \
-  do {                                                                                                \
-    if (ypro) hipLaunchKernelGGL((k_wgrad<T_, BT_, WM_, PRO_, true>), grid, block, 0, st, a);         \
-    else hipLaunchKernelGGL((k_wgrad<T_, BT_, WM_, PRO_, false>), grid, block, 0, st, a);             \
-  } while (0)
-#define FRX_WG_MODE(T_, BT_)                                              \
-  do {                                                                    \
-    if (wmode == WG_STEM) FRX_WG(T_, BT_, WG_STEM, false);                \
-    else if (wmode == WG_POINTWISE) { if (pro) FRX_WG(T_, BT_, WG_POINTWISE, true); else FRX_WG(T_, BT_, WG_POINTWISE, false); } \
-    else { if (pro) FRX_WG(T_, BT_, WG_GENERAL, true); else FRX_WG(T_, BT_, WG_GENERAL, false); }                               \
-  } while (0)
-  if (d->dtype == FRX_BF16) {
-    if (bt == 64) FRX_WG_MODE(bf16_t, 64); else FRX_WG_MODE(bf16_t, 128);
-  } else {
-    if (bt == 64) FRX_WG_MODE(float, 64); else FRX_WG_MODE(float, 128);
-  }
-#undef FRX_WG_MODE
-#undef FRX_WG
-  FRX_LAUNCH_CHECK();
-  return FRX_OK;
+  return launch_wgrad((hipStream_t)stream, a, d->dtype, bt, wmode, in_scale != nullptr, pro_y != nullptr, (int)grid.x);
 }
 
 extern "C" int frx_conv_wgrad(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x,

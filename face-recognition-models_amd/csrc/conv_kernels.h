@@ -22,7 +22,16 @@ template <typename T> struct TT;
 template <> struct TT<float>  { static constexpr int VEC = 4, CE = 16; };
 template <> struct TT<bf16_t> { static constexpr int VEC = 8, CE = 32; };
 
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 as_uint4(u32x4_t v) { return make_uint4(v[0], v[1], v[2], v[3]); }
+
 enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_STEM = 2 };
+// epilogue flavours of k_igemm
+enum { EPI_PLAIN = 0,       // store
+       EPI_STATS = 1,       // store + per-channel sum / sum of squares (train-mode BN statistics)
+       EPI_BNBWD = 2,       // dgrad: mask by e_scale*e_y+e_shift > 0, store dz, reduce sum(dz), sum(dz*xhat)
+       EPI_FC = 3,          // + bias, fp32 output (the fc layer)
+       EPI_BNBWD_OUT = 4 }; // as EPI_BNBWD with the merge-ReLU mask e_out > 0
 
 struct ConvArgs {
   const void* X;          // gathered operand: activations (fwd / wgrad) or dY (dgrad)
@@ -53,8 +62,25 @@ struct ConvArgs {
   unsigned xbytes, wbytes;   // sizes of X (and X2) and W in bytes: buffer-load bounds (out-of-range reads return 0)
 };
 
-typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ uint4 as_uint4(u32x4_t v) { return make_uint4(v[0], v[1], v[2], v[3]); }
+__device__ __forceinline__ void load8(const float* __restrict__ p, float (&o)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+}
+// 8 consecutive elements (ESZ bytes each) through a buffer descriptor, as floats; out-of-range -> 0
+template <int ESZ>
+__device__ __forceinline__ void buf_load8(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off, int soff, float (&o)[8]) {
+  if constexpr (ESZ == 4) {
+    const u32x4_t a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, soff, 0);
+    const u32x4_t b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off + 16u, soff, 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[e] = __uint_as_float(a[e]); o[4 + e] = __uint_as_float(b[e]); }
+  } else {
+    u32x4_t a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, soff, 0);
+    const bf16x8 h = *reinterpret_cast<bf16x8*>(&a);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (float)h[e];
+  }
+}
 
 // ds_read_b128 of a [rows][64 B] image is 2-way bank-conflicted for the 16x16x32 fragment
 // pattern (row = lane&15, chunk = lane>>4); XOR-ing the 16-byte chunk index with h[(row>>2)&3],
@@ -160,7 +186,7 @@ template <typename T> __device__ __forceinline__ float load_as_float(const void*
 // ------------------------------------------------------------------------------------------
 // MODE (gather geometry) and PRO (BN+ReLU prologue) are compile-time so the steady-state K loop is
 // straight-line code: hipcc then keeps counted s_waitcnt vmcnt(N) for the register ring.
-template <typename T, int BM, int BN, int WM, int WN, int MODE, int PRO>   // PRO: 0 none, 1 BN+ReLU, 2 BN-backward affine
+template <typename T, int BM, int BN, int WM, int WN, int MODE, int PRO, int EPI, bool ADD>   // PRO: 0 none, 1 BN+ReLU, 2 BN-backward affine
 __global__ __launch_bounds__(256, 2) void k_igemm(ConvArgs a) {   // 2 waves/SIMD: <= 256 VGPR+AGPR
   constexpr int VEC = TT<T>::VEC, CE = TT<T>::CE;
   constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 16, FN = WTN / 16;
@@ -192,6 +218,7 @@ __global__ __launch_bounds__(256, 2) void k_igemm(ConvArgs a) {   // 2 waves/SIM
   const int ldw = (MODE == MODE_STEM) ? a.R * 32 : Ktot;   // weight row length in elements
 
   // ---- per-thread gather bookkeeping (rows fixed across the K loop)
+  const bool pw = MODE != MODE_STEM && a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0;   // no index arithmetic needed
   int rn[ALD], rh[ALD], rw[ALD];
   bool rok[ALD];
 #pragma unroll
@@ -199,11 +226,18 @@ __global__ __launch_bounds__(256, 2) void k_igemm(ConvArgs a) {   // 2 waves/SIM
     const int m = m0 + srow + 64 * i;
     rok[i] = m < a.M;
     const int mm = rok[i] ? m : 0;
-    const int hw = a.Ho * a.Wo;
-    const int n = mm / hw, rem = mm - n * hw;
-    const int oh = rem / a.Wo, ow = rem - oh * a.Wo;
+    int n, oh, ow;
+    if (pw) {                                                    // pointwise: the gathered pixel IS pixel m
+      n = 0; oh = 0; ow = mm;
+    } else {
+      const int hw = a.Ho * a.Wo;
+      n = mm / hw;
+      const int rem = mm - n * hw;
+      oh = rem / a.Wo; ow = rem - oh * a.Wo;
+    }
     rn[i] = n;
-    if (MODE == MODE_FWD) { rh[i] = oh * a.stride - a.pad; rw[i] = ow * a.stride - a.pad; }
+    if (pw) { rh[i] = 0; rw[i] = mm; }
+    else if (MODE == MODE_FWD) { rh[i] = oh * a.stride - a.pad; rw[i] = ow * a.stride - a.pad; }
     else if (MODE == MODE_DGRAD) { rh[i] = oh + a.pad; rw[i] = ow + a.pad; }
     else { rh[i] = oh * 2; rw[i] = ow * 2; }
   }
@@ -247,7 +281,9 @@ __global__ __launch_bounds__(256, 2) void k_igemm(ConvArgs a) {   // 2 waves/SIM
     for (int i = 0; i < ALD; ++i) {
       bool ok = rok[i];
       int off;
-      if (MODE == MODE_FWD) {
+      if (pw) {
+        off = rw[i] * a.Kc;
+      } else if (MODE == MODE_FWD) {
         const int hi = rh[i] + tr, wi = rw[i] + ts;
         ok = ok && (unsigned)hi < (unsigned)a.Hx && (unsigned)wi < (unsigned)a.Wx;
         off = ((rn[i] * a.Hx + hi) * a.Wx + wi) * a.Kc;
@@ -408,8 +444,23 @@ __global__ __launch_bounds__(256, 2) void k_igemm(ConvArgs a) {   // 2 waves/SIM
   }
 
   // ---- epilogue.  C/D map: col = lane&15 (pixel), row = (lane>>4)*4 + reg (channel slot).
-  // Fragment pair (2a, 2a+1) holds, for this lane, channels 32a + 8*fq + [0..8): one 16-byte
-  // (bf16) or two 16-byte (fp32) stores per pixel instead of 8 scalar ones.
+  // Fragment pair (2a, 2a+1) holds, for this lane, channels 32a + 8*fq + [0..8) of pixel fr: 16-byte
+  // buffer stores.  The epilogue flavour is a template parameter and every access is a buffer access
+  // (rows past M fall outside the descriptor: loads give 0, stores are dropped), so this is
+  // straight-line code without per-element predicates; Ncol % BN == 0 is checked on the host.
+  constexpr bool OUT32 = (EPI == EPI_FC) || sizeof(T) == 4;
+  constexpr int OSZ = OUT32 ? 4 : 2;
+  const unsigned ybytes = (unsigned)a.M * (unsigned)a.Ncol * OSZ;
+  const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(a.Y, 0, ybytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcAdd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ADD ? a.addend : a.Y), 0, ybytes, 0x00020000);
+  const unsigned ebytes = (unsigned)a.M * (unsigned)a.Ncol * (unsigned)sizeof(T);
+  const __amdgpu_buffer_rsrc_t rsrcEy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>((EPI == EPI_BNBWD || EPI == EPI_BNBWD_OUT) ? a.e_y : a.Y), 0, ebytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcEo = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(EPI == EPI_BNBWD_OUT ? a.e_out : a.Y), 0, ebytes, 0x00020000);
+  const int mrow = m0 + wm * WTM + fr;                          // this lane's pixel row for fragment i = 0
+  const int ncol0 = n0 + wn * WTN + 8 * fq;                     // first of its 8 channels for pair a2 = 0
+  const unsigned elem0 = (unsigned)mrow * (unsigned)a.Ncol + (unsigned)ncol0;   // element index of (mrow, ncol0)
+  const unsigned rstep = 16u * (unsigned)a.Ncol;                // elements between fragment rows (scalar)
+  constexpr bool STATS = (EPI == EPI_STATS || EPI == EPI_BNBWD || EPI == EPI_BNBWD_OUT);
   float csum[FN][4], csq[FN][4];
 #pragma unroll
   for (int j = 0; j < FN; ++j)
@@ -417,106 +468,69 @@ __global__ __launch_bounds__(256, 2) void k_igemm(ConvArgs a) {   // 2 waves/SIM
     for (int r = 0; r < 4; ++r) { csum[j][r] = 0.f; csq[j][r] = 0.f; }
 #pragma unroll
   for (int a2 = 0; a2 < FN / 2; ++a2) {
-    const int nb = n0 + wn * WTN + 32 * a2 + 8 * fq;          // first of this lane's 8 channels
-    const bool nok = nb < a.Ncol;                              // Ncol % 8 == 0 (checked on the host)
-    float bias[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (a.bias != nullptr && nok) {
-      const float4 b0 = *reinterpret_cast<const float4*>(a.bias + nb), b1 = *reinterpret_cast<const float4*>(a.bias + nb + 4);
-      bias[0] = b0.x; bias[1] = b0.y; bias[2] = b0.z; bias[3] = b0.w; bias[4] = b1.x; bias[5] = b1.y; bias[6] = b1.z; bias[7] = b1.w;
-    }
-    // BN-backward epilogue constants of this lane's 8 channels
-    float emu[8], eis[8], esc[8], esh[8];
-    if (a.epi_bnbwd && nok) {
-#pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        const float4 x = *reinterpret_cast<const float4*>(a.e_mean + nb + 4 * q), y = *reinterpret_cast<const float4*>(a.e_invstd + nb + 4 * q);
-        emu[4 * q] = x.x; emu[4 * q + 1] = x.y; emu[4 * q + 2] = x.z; emu[4 * q + 3] = x.w;
-        eis[4 * q] = y.x; eis[4 * q + 1] = y.y; eis[4 * q + 2] = y.z; eis[4 * q + 3] = y.w;
-        if (a.e_out == nullptr) {
-          const float4 z = *reinterpret_cast<const float4*>(a.e_scale + nb + 4 * q), w = *reinterpret_cast<const float4*>(a.e_shift + nb + 4 * q);
-          esc[4 * q] = z.x; esc[4 * q + 1] = z.y; esc[4 * q + 2] = z.z; esc[4 * q + 3] = z.w;
-          esh[4 * q] = w.x; esh[4 * q + 1] = w.y; esh[4 * q + 2] = w.z; esh[4 * q + 3] = w.w;
-        }
-      }
-    }
+    const int nb = ncol0 + 32 * a2;
+    float bias[8], emu[8], eis[8], esc[8], esh[8];
+    if constexpr (EPI == EPI_FC) load8(a.bias + nb, bias);
+    if constexpr (EPI == EPI_BNBWD || EPI == EPI_BNBWD_OUT) { load8(a.e_mean + nb, emu); load8(a.e_invstd + nb, eis); }
+    if constexpr (EPI == EPI_BNBWD) { load8(a.e_scale + nb, esc); load8(a.e_shift + nb, esh); }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-      const int m = m0 + wm * WTM + i * 16 + fr;
-      if (m < a.M && nok) {
-        float v[8];
+      const unsigned eoff = elem0 + 32u * a2;                  // + i*rstep goes into the scalar offset
+      const int so_t = (int)(i * rstep * sizeof(T)), so_o = (int)(i * rstep * OSZ);
+      float v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * a2 + (e >> 2)][e & 3] + bias[e];
-        const long o = (long)m * a.Ncol + nb;
-        float yv[8];            // epi_bnbwd: raw conv output of the BN layer being back-propagated
-        bool on[8];
-        if (a.addend) {
-          if (a.out_f32 || sizeof(T) == 4) {
-            const float4 p0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.addend) + o);
-            const float4 p1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.addend) + o + 4);
-            v[0] += p0.x; v[1] += p0.y; v[2] += p0.z; v[3] += p0.w; v[4] += p1.x; v[5] += p1.y; v[6] += p1.z; v[7] += p1.w;
-          } else {
-            const uint4 praw = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.addend) + o);
-            const bf16x8 p = *reinterpret_cast<const bf16x8*>(&praw);
+      for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * a2 + (e >> 2)][e & 3];
+      if constexpr (EPI == EPI_FC) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] += (float)p[e];
-          }
-        }
-        if (a.epi_bnbwd) {
-          if constexpr (sizeof(T) == 4) {
-            const float4 y0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.e_y) + o);
-            const float4 y1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.e_y) + o + 4);
-            yv[0] = y0.x; yv[1] = y0.y; yv[2] = y0.z; yv[3] = y0.w; yv[4] = y1.x; yv[5] = y1.y; yv[6] = y1.z; yv[7] = y1.w;
-            if (a.e_out) {
-              const float4 o0 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.e_out) + o);
-              const float4 o1 = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(a.e_out) + o + 4);
-              on[0] = o0.x > 0.f; on[1] = o0.y > 0.f; on[2] = o0.z > 0.f; on[3] = o0.w > 0.f;
-              on[4] = o1.x > 0.f; on[5] = o1.y > 0.f; on[6] = o1.z > 0.f; on[7] = o1.w > 0.f;
-            }
-          } else {
-            const uint4 yr = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.e_y) + o);
-            const bf16x8 yb = *reinterpret_cast<const bf16x8*>(&yr);
+        for (int e = 0; e < 8; ++e) v[e] += bias[e];
+      }
+      if constexpr (ADD) {
+        float av[8];
+        buf_load8<OUT32 ? 4 : 2>(rsrcAdd, eoff * OSZ, so_o, av);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) yv[e] = (float)yb[e];
-            if (a.e_out) {
-              const uint4 orr = *reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(a.e_out) + o);
-              const bf16x8 ob = *reinterpret_cast<const bf16x8*>(&orr);
+        for (int e = 0; e < 8; ++e) v[e] += av[e];
+      }
+      float yv[8];
+      if constexpr (EPI == EPI_BNBWD || EPI == EPI_BNBWD_OUT) {
+        buf_load8<sizeof(T)>(rsrcEy, eoff * (unsigned)sizeof(T), so_t, yv);
+        if constexpr (EPI == EPI_BNBWD_OUT) {
+          float ov[8];
+          buf_load8<sizeof(T)>(rsrcEo, eoff * (unsigned)sizeof(T), so_t, ov);
 #pragma unroll
-              for (int e = 0; e < 8; ++e) on[e] = (float)ob[e] > 0.f;
-            }
-          }
-          if (!a.e_out) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) on[e] = fmaf(yv[e], esc[e], esh[e]) > 0.f;
-          }
-#pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = on[e] ? v[e] : 0.f;
-        }
-        if (a.out_f32 || sizeof(T) == 4) {
-          float* yo = reinterpret_cast<float*>(a.Y) + o;
-          *reinterpret_cast<float4*>(yo) = make_float4(v[0], v[1], v[2], v[3]);
-          *reinterpret_cast<float4*>(yo + 4) = make_float4(v[4], v[5], v[6], v[7]);
-        } else {
-          bf16x8 t;
-#pragma unroll
-          for (int e = 0; e < 8; ++e) { t[e] = (bf16_t)v[e]; v[e] = (float)t[e]; }   // stats of what the next layer reads
-          *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(a.Y) + o) = *reinterpret_cast<uint4*>(&t);
-        }
-        if (a.epi_bnbwd) {
-#pragma unroll
-          for (int e = 0; e < 8; ++e) {
-            csum[2 * a2 + (e >> 2)][e & 3] += v[e];
-            csq[2 * a2 + (e >> 2)][e & 3] += v[e] * (yv[e] - emu[e]) * eis[e];
-          }
+          for (int e = 0; e < 8; ++e) v[e] = ov[e] > 0.f ? v[e] : 0.f;
         } else {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) { csum[2 * a2 + (e >> 2)][e & 3] += v[e]; csq[2 * a2 + (e >> 2)][e & 3] += v[e] * v[e]; }
+          for (int e = 0; e < 8; ++e) v[e] = fmaf(yv[e], esc[e], esh[e]) > 0.f ? v[e] : 0.f;
+        }
+      }
+      if constexpr (OUT32) {
+        u32x4_t s0, s1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { s0[e] = __float_as_uint(v[e]); s1[e] = __float_as_uint(v[4 + e]); }
+        __builtin_amdgcn_raw_buffer_store_b128(s0, rsrcY, eoff * 4u, so_o, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(s1, rsrcY, eoff * 4u + 16u, so_o, 0);
+      } else {
+        bf16x8 t;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { t[e] = (bf16_t)v[e]; v[e] = (float)t[e]; }   // stats of what the next layer reads
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<u32x4_t*>(&t), rsrcY, eoff * 2u, so_o, 0);
+      }
+      if constexpr (EPI == EPI_STATS) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { csum[2 * a2 + (e >> 2)][e & 3] += v[e]; csq[2 * a2 + (e >> 2)][e & 3] += v[e] * v[e]; }
+      }
+      if constexpr (EPI == EPI_BNBWD || EPI == EPI_BNBWD_OUT) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          csum[2 * a2 + (e >> 2)][e & 3] += v[e];
+          csq[2 * a2 + (e >> 2)][e & 3] += v[e] * (yv[e] - emu[e]) * eis[e];
         }
       }
     }
   }
-  if (a.stat_partial) {
-    // Reduce over the 16 pixel-lanes with a halving butterfly: after the steps, lane fr holds the
-    // total of value index (fr % NV), NV = FN*4 values per lane.
+  if constexpr (STATS) {
+    // Reduce over the 16 pixel-lanes with a halving butterfly: afterwards lane fr holds the total of
+    // value index (fr % NV), NV = FN*4 values per lane.
     constexpr int NV = FN * 4;
     float vs[NV], vq[NV];
 #pragma unroll
@@ -535,12 +549,10 @@ __global__ __launch_bounds__(256, 2) void k_igemm(ConvArgs a) {   // 2 waves/SIM
     __syncthreads();
     for (int t = tid; t < 2 * BN; t += 256) {
       const int which = t / BN, col = t % BN;
-      if (n0 + col < a.Ncol) {
-        float sum = 0.f;
+      float sum = 0.f;
 #pragma unroll
-        for (int w = 0; w < WM; ++w) sum += red[(which * WM + w) * BN + col];
-        a.stat_partial[((long)mt * 2 + which) * a.Ncol + n0 + col] = sum;
-      }
+      for (int w = 0; w < WM; ++w) sum += red[(which * WM + w) * BN + col];
+      a.stat_partial[((long)mt * 2 + which) * a.Ncol + n0 + col] = sum;
     }
   }
 }

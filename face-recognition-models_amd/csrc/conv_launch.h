@@ -1,0 +1,37 @@
+// Launch plumbing shared by the convolution translation units (the kernel templates are instantiated
+// in several .hip files so that `make -j` compiles them in parallel).
+#pragma once
+#include "conv_kernels.h"
+
+namespace frx {
+
+struct TileCfg { int bm, bn; };
+
+static inline TileCfg pick_tile(long M, int Ncol) {
+  if (Ncol <= 64) return {128, 64};
+  const long tiles128 = ((M + 127) / 128) * ((Ncol + 127) / 128);
+  if (tiles128 < 384) return {64, 64};     // small problems: fill the 256 CUs
+  return {128, 128};
+}
+
+// each returns FRX_OK / FRX_ERR_*; `a` is completed (tiles, byte sizes) by the caller
+int launch_igemm_fwd(hipStream_t st, const ConvArgs& a, int dtype, TileCfg c, int grid, int pro, int epi);
+int launch_igemm_stem(hipStream_t st, const ConvArgs& a, int dtype, TileCfg c, int grid, int epi);
+int launch_igemm_dgrad_plain(hipStream_t st, const ConvArgs& a, int dtype, TileCfg c, int grid, int epi, bool add);
+int launch_igemm_dgrad_bn(hipStream_t st, const ConvArgs& a, int dtype, TileCfg c, int grid, int epi, bool add);
+
+int launch_wgrad(hipStream_t st, const WgradArgs& a, int dtype, int bt, int wmode, bool pro, bool ypro, int grid);
+
+#define FRX_IGEMM_LAUNCH(T_, MODE_, PRO_, EPI_, ADD_)                                                                     \
+  do {                                                                                                                    \
+    if (c.bm == 128 && c.bn == 128) hipLaunchKernelGGL((k_igemm<T_, 128, 128, 2, 2, MODE_, PRO_, EPI_, ADD_>), dim3(grid), dim3(256), 0, st, a); \
+    else if (c.bm == 128 && c.bn == 64) hipLaunchKernelGGL((k_igemm<T_, 128, 64, 2, 2, MODE_, PRO_, EPI_, ADD_>), dim3(grid), dim3(256), 0, st, a); \
+    else hipLaunchKernelGGL((k_igemm<T_, 64, 64, 2, 2, MODE_, PRO_, EPI_, ADD_>), dim3(grid), dim3(256), 0, st, a);       \
+  } while (0)
+#define FRX_IGEMM_DT(MODE_, PRO_, EPI_, ADD_)                                   \
+  do {                                                                          \
+    if (dtype == FRX_BF16) FRX_IGEMM_LAUNCH(bf16_t, MODE_, PRO_, EPI_, ADD_);   \
+    else FRX_IGEMM_LAUNCH(float, MODE_, PRO_, EPI_, ADD_);                      \
+  } while (0)
+
+}  // namespace frx
