@@ -507,13 +507,16 @@ __global__ __launch_bounds__(256, 2) void k_igemm(ConvArgs a) {   // 2 waves/SIM
         u32x4_t s0, s1;
 #pragma unroll
         for (int e = 0; e < 4; ++e) { s0[e] = __float_as_uint(v[e]); s1[e] = __float_as_uint(v[4 + e]); }
-        __builtin_amdgcn_raw_buffer_store_b128(s0, rsrcY, eoff * 4u, so_o, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(s1, rsrcY, eoff * 4u + 16u, so_o, 0);
+        // NOTE soffset must stay the literal 0 on stores: with an SGPR soffset hipcc (ROCm 7.2) assumes the
+        // ">64-bit store data overwritten by the next VALU" hazard away and re-uses the data registers in
+        // the very next instruction; on gfx950 that corrupts sporadic dwords once several blocks share a CU.
+        __builtin_amdgcn_raw_buffer_store_b128(s0, rsrcY, eoff * 4u + (unsigned)so_o, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(s1, rsrcY, eoff * 4u + (unsigned)so_o + 16u, 0, 0);
       } else {
         bf16x8 t;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { t[e] = (bf16_t)v[e]; v[e] = (float)t[e]; }   // stats of what the next layer reads
-        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<u32x4_t*>(&t), rsrcY, eoff * 2u, so_o, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<u32x4_t*>(&t), rsrcY, eoff * 2u + (unsigned)so_o, 0, 0);
       }
       if constexpr (EPI == EPI_STATS) {
 #pragma unroll
@@ -539,7 +542,7 @@ __global__ __launch_bounds__(256, 2) void k_igemm(ConvArgs a) {   // 2 waves/SIM
       for (int r = 0; r < 4; ++r) { vs[j * 4 + r] = csum[j][r]; vq[j * 4 + r] = csq[j][r]; }
     lane16_butterfly<NV, 8>(vs, vq, fr);
     // lane fr now owns value index vi = fr % NV  ->  fragment j = vi>>2, reg r = vi&3
-    float* red = reinterpret_cast<float*>(smem);   // [2][WM][BN]; the K loop ended with a barrier
+    __shared__ float red[2 * WM * BN];             // [2][WM][BN]
     if (fr < NV) {
       const int j = fr >> 2, r = fr & 3;
       const int col = wn * WTN + 32 * (j >> 1) + 8 * fq + 4 * (j & 1) + r;

@@ -202,3 +202,31 @@ def test_fused_bn_backward_in_dgrad_wgrad(dtype, shape, merge_mask):
     dw = torch.zeros_like(dw_ref)
     ops.conv_wgrad_bn(d, x, dz, y, coef, dw, in_scale=sc, in_shift=sh, in_relu=True)
     _close(dw, dw_ref.cpu(), dtype, "fused wgrad")
+
+
+@pytest.mark.parametrize("dtype", [0, 1], ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(64, 64, 1, 28), (64, 256, 1, 28), (64, 64, 3, 28)], ids=lambda s: f"{s[0]}x{s[1]}k{s[2]}")
+def test_conv_many_coresident_blocks(dtype, shape):
+    """Batch 64: thousands of short blocks, several per CU.  Guards a hazard met on gfx950 / ROCm 7.2: a
+    buffer_store_dwordx4 with an SGPR soffset whose data registers hipcc re-used in the next instruction
+    corrupted sporadic dwords only when blocks were co-resident (small-batch tests never saw it)."""
+    from frx import ops
+    Ci, Co, k, Hi = shape
+    N = 64
+    d = ops.conv_desc(dtype, N, Hi, Hi, Ci, Co, k, k, 1, k // 2)
+    T = ops.TORCH_DT[dtype]
+    x, w = _mk(dtype, N, Hi, Hi, Ci, seed=1), _mk(dtype, Co, k, k, Ci, scale=0.1, seed=2)
+    ref = F.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), padding=k // 2).permute(0, 2, 3, 1)
+    xd, wd = x.to(DEV), w.to(DEV)
+    one, zero = torch.ones(Ci, device=DEV), torch.zeros(Ci, device=DEV)
+    for stats in (False, True):
+        for pro in (False, True):
+            y = torch.zeros(N, Hi, Hi, Co, dtype=T, device=DEV)
+            part = torch.zeros(ops.conv_stat_rows(d), 2, Co, device=DEV) if stats else None
+            kw = dict(in_scale=one, in_shift=zero, in_relu=False) if pro else {}
+            ops.conv_fwd(d, xd, wd, y, stat_partial=part, **kw)
+            err = (y.float().cpu() - ref).abs()
+            bad = int((~(err < 0.1 + 0.02 * ref.abs())).sum())
+            assert bad == 0, f"stats={stats} pro={pro}: {bad} corrupted outputs"
+            if stats:
+                _close(part[:, 0].sum(0), y.float().cpu().sum((0, 1, 2)), 0, "stat sum")
