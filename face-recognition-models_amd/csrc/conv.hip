@@ -3,6 +3,7 @@
 // reference builds in main_code/utils/backbones.py:16-18, forward and autograd backward
 // (main_code/utils/criterion.py:320, model_utils.py:177,185).
 #include "conv_launch.h"
+#include <stdlib.h>
 
 namespace frx {
 
@@ -177,8 +178,11 @@ static int wgrad_impl(int device, frx_stream_t stream, const frx_conv_desc* d, c
   const int tiles = a.tilesCo * a.tilesCi * taps;
   // Split the pixel axis so ~3 blocks per CU exist, but keep >= 16 K-chunks per block (below that
   // the 64-atomics-per-lane epilogue dominates); round to a multiple of 8 for the XCD mapping.
-  int splits = cdiv(768, tiles);
-  if (splits > nchunks / 16) splits = nchunks / 16;
+  const char* env_b = getenv("FRX_WGRAD_BLOCKS");
+  const char* env_c = getenv("FRX_WGRAD_MINCHUNKS");
+  const int target_blocks = env_b ? atoi(env_b) : 512, min_chunks = env_c ? atoi(env_c) : 32;   // measured sweep (atomics vs occupancy)
+  int splits = cdiv(target_blocks, tiles);
+  if (splits > nchunks / min_chunks) splits = nchunks / min_chunks;
   if (splits >= 8) splits = splits / 8 * 8;
   if (splits < 1) splits = 1;
   a.chunks_per_split = cdiv(nchunks, splits);
