@@ -473,10 +473,20 @@ __global__ __launch_bounds__(256, 2) void k_igemm(ConvArgs a) {   // 2 waves/SIM
     if constexpr (EPI == EPI_FC) load8(a.bias + nb, bias);
     if constexpr (EPI == EPI_BNBWD || EPI == EPI_BNBWD_OUT) { load8(a.e_mean + nb, emu); load8(a.e_invstd + nb, eis); }
     if constexpr (EPI == EPI_BNBWD) { load8(a.e_scale + nb, esc); load8(a.e_shift + nb, esh); }
+    // Issue every epilogue load of this channel pair first (up to 3 tensors x FM fragments in flight),
+    // then consume: one memory round trip per pair instead of one per fragment.
+    const unsigned eoff = elem0 + 32u * a2;                    // + i*rstep goes into the scalar offset
+    float av[ADD ? FM : 1][8], yv[(EPI == EPI_BNBWD || EPI == EPI_BNBWD_OUT) ? FM : 1][8], ov[EPI == EPI_BNBWD_OUT ? FM : 1][8];
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-      const unsigned eoff = elem0 + 32u * a2;                  // + i*rstep goes into the scalar offset
       const int so_t = (int)(i * rstep * sizeof(T)), so_o = (int)(i * rstep * OSZ);
+      if constexpr (ADD) buf_load8<OUT32 ? 4 : 2>(rsrcAdd, eoff * OSZ, so_o, av[i]);
+      if constexpr (EPI == EPI_BNBWD || EPI == EPI_BNBWD_OUT) buf_load8<sizeof(T)>(rsrcEy, eoff * (unsigned)sizeof(T), so_t, yv[i]);
+      if constexpr (EPI == EPI_BNBWD_OUT) buf_load8<sizeof(T)>(rsrcEo, eoff * (unsigned)sizeof(T), so_t, ov[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int so_o = (int)(i * rstep * OSZ);
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * a2 + (e >> 2)][e & 3];
@@ -485,23 +495,16 @@ __global__ __launch_bounds__(256, 2) void k_igemm(ConvArgs a) {   // 2 waves/SIM
         for (int e = 0; e < 8; ++e) v[e] += bias[e];
       }
       if constexpr (ADD) {
-        float av[8];
-        buf_load8<OUT32 ? 4 : 2>(rsrcAdd, eoff * OSZ, so_o, av);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += av[e];
+        for (int e = 0; e < 8; ++e) v[e] += av[i][e];
       }
-      float yv[8];
-      if constexpr (EPI == EPI_BNBWD || EPI == EPI_BNBWD_OUT) {
-        buf_load8<sizeof(T)>(rsrcEy, eoff * (unsigned)sizeof(T), so_t, yv);
-        if constexpr (EPI == EPI_BNBWD_OUT) {
-          float ov[8];
-          buf_load8<sizeof(T)>(rsrcEo, eoff * (unsigned)sizeof(T), so_t, ov);
+      if constexpr (EPI == EPI_BNBWD_OUT) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = ov[e] > 0.f ? v[e] : 0.f;
-        } else {
+        for (int e = 0; e < 8; ++e) v[e] = ov[i][e] > 0.f ? v[e] : 0.f;
+      }
+      if constexpr (EPI == EPI_BNBWD) {
 #pragma unroll
-          for (int e = 0; e < 8; ++e) v[e] = fmaf(yv[e], esc[e], esh[e]) > 0.f ? v[e] : 0.f;
-        }
+        for (int e = 0; e < 8; ++e) v[e] = fmaf(yv[i][e], esc[e], esh[e]) > 0.f ? v[e] : 0.f;
       }
       if constexpr (OUT32) {
         u32x4_t s0, s1;
@@ -526,7 +529,7 @@ __global__ __launch_bounds__(256, 2) void k_igemm(ConvArgs a) {   // 2 waves/SIM
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           csum[2 * a2 + (e >> 2)][e & 3] += v[e];
-          csq[2 * a2 + (e >> 2)][e & 3] += v[e] * (yv[e] - emu[e]) * eis[e];
+          csq[2 * a2 + (e >> 2)][e & 3] += v[e] * (yv[i][e] - emu[e]) * eis[e];
         }
       }
     }

@@ -9,9 +9,11 @@ struct TileCfg { int bm, bn; };
 
 static inline TileCfg pick_tile(long M, int Ncol) {
   if (Ncol <= 64) return {128, 64};
-  const long tiles128 = ((M + 127) / 128) * ((Ncol + 127) / 128);
-  if (tiles128 < 384) return {64, 64};     // small problems: fill the 256 CUs
-  return {128, 128};
+  const long mt128 = (M + 127) / 128;
+  if (mt128 * ((Ncol + 127) / 128) >= 384) return {128, 128};
+  // small problems: keep the 256 CUs busy, but prefer the taller tile (more MFMA per LDS byte)
+  if (mt128 * ((Ncol + 63) / 64) >= 256) return {128, 64};
+  return {64, 64};
 }
 
 // each returns FRX_OK / FRX_ERR_*; `a` is completed (tiles, byte sizes) by the caller

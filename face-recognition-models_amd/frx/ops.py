@@ -34,9 +34,12 @@ def _igemm_tile(M, ncol):
     """mirror of pick_tile() in csrc/conv.hip (only used to label profiled launches)"""
     if ncol <= 64:
         return 128, 64
-    if ((M + 127) // 128) * ((ncol + 127) // 128) < 384:
-        return 64, 64
-    return 128, 128
+    mt = (M + 127) // 128
+    if mt * ((ncol + 127) // 128) >= 384:
+        return 128, 128
+    if mt * ((ncol + 63) // 64) >= 256:
+        return 128, 64
+    return 64, 64
 
 
 def _dt_name(dt):
