@@ -49,6 +49,37 @@ __global__ __launch_bounds__(256) void k_weight_prep(int Co, int RS, int Ci, con
   }
 }
 
+// All layers in ONE launch: table [n][8] of int64 = {src offset (floats), Co, RS, Ci, krsc ptr, crsk ptr,
+// first block, unused}; each block owns 1024 consecutive elements of one layer.
+template <typename T>
+__global__ __launch_bounds__(256) void k_weight_prep_batched(int n, const int64_t* __restrict__ table,
+                                                             const float* __restrict__ master) {
+  int e = 0;
+  for (int i = 1; i < n; ++i) e = ((int64_t)blockIdx.x >= table[i * 8 + 6]) ? i : e;   // tables are ~55 entries
+  const int64_t* t = table + e * 8;
+  const float* w = master + t[0];
+  const int Co = (int)t[1], RS = (int)t[2], Ci = (int)t[3];
+  T* krsc = reinterpret_cast<T*>(t[4]);
+  T* crsk = reinterpret_cast<T*>(t[5]);
+  const long total = (long)Co * RS * Ci;
+  const long base = ((long)blockIdx.x - t[6]) * 1024;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const long i = base + threadIdx.x + 256 * k;
+    if (i < total) {
+      const float v = w[i];
+      if (krsc) krsc[i] = (T)v;
+      if (crsk) {
+        const int ci = (int)(i % Ci);
+        const long q = i / Ci;
+        const int rs = (int)(q % RS);
+        const int co = (int)(q / RS);
+        crsk[((long)ci * RS + rs) * Co + co] = (T)v;
+      }
+    }
+  }
+}
+
 // fp32 NCHW image batch (already normalised to [-1,1]) -> zero-bordered NHWC4 in T for the stem
 template <typename T>
 __global__ __launch_bounds__(256) void k_input_prep_f32(int N, int H, int W, int Hp, int Wp,
@@ -190,6 +221,19 @@ extern "C" int frx_colsum_f32(int device, frx_stream_t stream, int rows, int C, 
   FRX_CHECK_ARG(x && out && rows > 0 && C > 0, "colsum: bad args");
   FRX_ENTER(device);
   hipLaunchKernelGGL(k_colsum_f32, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, rows, C, x, out);
+  FRX_LAUNCH_CHECK();
+  return FRX_OK;
+}
+
+extern "C" int frx_weight_prep_batched(int device, frx_stream_t stream, int dtype, int n, const int64_t* table_dev,
+                                       const float* master, int total_blocks) {
+  FRX_CHECK_ARG(dtype == FRX_F32 || dtype == FRX_BF16, "weight_prep_batched: dtype");
+  FRX_CHECK_ARG(n > 0 && table_dev && master && total_blocks > 0, "weight_prep_batched: bad args");
+  FRX_ENTER(device);
+  if (dtype == FRX_BF16)
+    hipLaunchKernelGGL(k_weight_prep_batched<bf16_t>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, n, table_dev, master);
+  else
+    hipLaunchKernelGGL(k_weight_prep_batched<float>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, n, table_dev, master);
   FRX_LAUNCH_CHECK();
   return FRX_OK;
 }

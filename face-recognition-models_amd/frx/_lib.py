@@ -70,6 +70,7 @@ _SIGS = {
     "frx_avgpool_bwd": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "frx_sgd_step": (C.c_int, [C.c_int, _P, C.c_int64, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float]),
     "frx_weight_prep": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
+    "frx_weight_prep_batched": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, _P, _P, C.c_int]),
     "frx_input_prep": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
     "frx_cast": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int64, _P, _P]),
     "frx_colsum_f32": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, _P, _P]),

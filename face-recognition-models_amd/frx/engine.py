@@ -235,17 +235,28 @@ class ResNet50Engine:
         self.mom.zero_()
         self.sync_weights()
 
-    def sync_weights(self):
-        """fp32 master -> kernel-format copies (after an optimiser step or a state-dict load)."""
+    def _build_prep_table(self):
+        rows, blk = [], 0
         for c in self.convs:
-            if c.stem:
-                m = self.w_master(c)
-                m[:, :, 7, :] = 0          # the 8th tap / 4th channel exist only as padding
-                m[..., 3] = 0
-                ops.cast(self.dtype, m, c.wk, to_f32=False)
+            if c.stem:      # [64][7][8][4] is copied as-is (KRSC with RS*Ci = 224)
+                ent = (c.w_off, 64, 1, 224, c.wk.data_ptr(), 0)
             else:
-                ops.weight_prep(self.dtype, c.Co, c.k * c.k, c.Ci, self.w_master(c), krsc=c.wk, crsk=c.wt)
-        ops.weight_prep(self.dtype, FEATURE_DIM, 1, 2048, self.fc_w(), krsc=self.fc_wk, crsk=self.fc_wt)
+                ent = (c.w_off, c.Co, c.k * c.k, c.Ci, c.wk.data_ptr(), c.wt.data_ptr())
+            rows.append(ent + (blk, 0))
+            blk += (ent[1] * ent[2] * ent[3] + 1023) // 1024
+        rows.append((self.fc_w_off, FEATURE_DIM, 1, 2048, self.fc_wk.data_ptr(), self.fc_wt.data_ptr(), blk, 0))
+        blk += (FEATURE_DIM * 2048 + 1023) // 1024
+        self._prep_table = torch.tensor(rows, dtype=torch.int64, device=self.device)
+        self._prep_blocks = blk
+
+    def sync_weights(self):
+        """fp32 master -> kernel-format copies (after an optimiser step or a state-dict load): one launch."""
+        m = self.w_master(self.stem)
+        m[:, :, 7, :] = 0          # the stem's 8th tap / 4th channel exist only as padding
+        m[..., 3] = 0
+        if getattr(self, "_prep_table", None) is None:
+            self._build_prep_table()
+        ops.weight_prep_batched(self.dtype, self._prep_table, self.params, self._prep_blocks)
         owner = self.share or self
         owner.weights_version = getattr(owner, "weights_version", 0) + 1
 

@@ -308,6 +308,11 @@ def weight_prep(dtype, Co, RS, Ci, master, krsc=None, crsk=None):
           "frx_weight_prep")
 
 
+def weight_prep_batched(dtype, table, master, total_blocks):
+    check(_lib.lib().frx_weight_prep_batched(_dev(master), _stream(master), dtype, table.shape[0], _p(table), _p(master),
+                                             total_blocks), "frx_weight_prep_batched")
+
+
 def input_prep(dtype, images, out):
     if images.dtype == torch.uint8:
         N, H, W, _ = images.shape

@@ -209,6 +209,10 @@ int frx_sgd_step(int device, frx_stream_t stream, int64_t n, float* p, const flo
                  const float* lr_dev, float lr, float momentum, float weight_decay, float grad_scale);
 int frx_weight_prep(int device, frx_stream_t stream, int dtype, int Co, int RS, int Ci, const float* master_krsc,
                     void* krsc, void* crsk);
+/* every layer in one launch: table_dev [n][8] int64 = {offset of the layer's KRSC master in `master` (floats), Co, RS,
+ * Ci, krsc pointer or 0, crsk pointer or 0, index of the layer's first block, 0}; a block covers 1024 elements */
+int frx_weight_prep_batched(int device, frx_stream_t stream, int dtype, int n, const int64_t* table_dev,
+                            const float* master, int total_blocks);
 int frx_input_prep(int device, frx_stream_t stream, int dtype, int N, int H, int W, const void* images,
                    int is_u8_nhwc, void* out);
 int frx_cast(int device, frx_stream_t stream, int dtype, int to_f32, int64_t n, const void* x, void* y);
