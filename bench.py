@@ -84,6 +84,22 @@ def kernel_pass(eng, images, labels, steps=3):
 
 
 def main():
+    # Everything except the final JSON line goes to stderr -- including what native libraries (RCCL prints a
+    # version banner at init) write to file descriptor 1.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        result = run()
+    finally:
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        os.close(real_stdout)
+    if result is not None:
+        print(json.dumps(result), flush=True)
+
+
+def run():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -94,6 +110,8 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--lr", type=float, default=0.02)
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--split", action="store_true",
+                    help="run the data-parallel step structure (3 graphs + async all-reduce) even on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -107,15 +125,16 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     import torch.distributed as dist
-    if world > 1:
+    if world > 1 or args.split:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29512")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from frx import ddp, engine as E, ops
     dt = ops.BF16 if args.dtype == "bf16" else ops.F32
     eng = E.FaceEngine(args.head, args.classes, args.batch, dtype=dt, device=dev, seed=0)   # same init on all ranks
     if world > 1:
-        ddp.attach(eng)
+        eng.world = world            # grad_scale 1/world in the fused SGD; the all-reduce is issued by the step below
     g = torch.Generator().manual_seed(1234 + rank)
     nb = 4
     batches = [((torch.rand(args.batch, 3, 112, 112, generator=g) * 2 - 1).to(dev),
@@ -131,25 +150,66 @@ def main():
         labels.copy_(batches[i % nb][1])
 
     log(f"engine ready: {eng.net.n_params} parameters, batch {args.batch}, world {world}")
-    use_graph = (not args.no_graph) and world == 1
+    ddp_mode = world > 1 or args.split
+    use_graph = not args.no_graph
     graph = None
-    if use_graph:
-        side = torch.cuda.Stream()
-        feed(0)
+    side = torch.cuda.Stream()
+
+    def capture(fn):
+        """warm up on a side stream, then capture fn into a hipGraph"""
         with torch.cuda.stream(side):
-            eng.train_step(images, labels)
+            fn()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            out = eng.train_step(images, labels)
+        g_ = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g_):
+            r = fn()
+        return g_, r
 
-    def step(i):
-        feed(i)
-        if graph is not None:
-            graph.replay()
-            return out
-        return eng.train_step(images, labels)
+    if ddp_mode:
+        # step = [graph: zero, forward, CE, head + layer4/3 backward] -> async all-reduce of the upper gradient
+        # ranges (overlaps) -> [graph: layer2/1/stem backward] -> all-reduce of the rest -> [graph: SGD + weight prep]
+        rng = eng.net.grad_ranges()
+        grads = eng.net.grads
+        feed(0)
+        if use_graph:
+            eng.step_upper(images, labels); eng.step_lower(); eng.step_update()      # allocate / warm every path once
+            g_up, out = capture(lambda: eng.step_upper(images, labels))
+            g_lo, _ = capture(eng.step_lower)
+            g_sgd, _ = capture(eng.step_update)
+            graph = g_up
+
+        def step(i):
+            feed(i)
+            o_ = out
+            if use_graph:
+                g_up.replay()
+            else:
+                o_ = eng.step_upper(images, labels)
+            works = [dist.all_reduce(grads[lo:hi], async_op=True) for lo, hi in rng["upper"]]
+            if use_graph:
+                g_lo.replay()
+            else:
+                eng.step_lower()
+            works += [dist.all_reduce(grads[lo:hi], async_op=True) for lo, hi in rng["lower"]]
+            for w_ in works:
+                w_.wait()
+            if use_graph:
+                g_sgd.replay()
+            else:
+                eng.step_update()
+            return o_
+    else:
+        if use_graph:
+            feed(0)
+            graph, out = capture(lambda: eng.train_step(images, labels))
+
+        def step(i):
+            feed(i)
+            if graph is not None:
+                graph.replay()
+                return out
+            return eng.train_step(images, labels)
 
     log("graph captured" if graph is not None else "eager mode")
     for i in range(args.warmup):
@@ -175,7 +235,7 @@ def main():
     if rank == 0:
         ips = world * args.batch * args.steps / dt_s
         flop_img = FLOP_PER_IMG_BACKBONE + 6.0 * 512 * args.classes
-        agg = kernel_pass(eng, images, labels) if world == 1 else {}
+        agg = kernel_pass(eng, images, labels) if world == 1 else {}      # (eng.allreduce is unset: plain single-GPU step)
         roof = None
         if agg:
             label, (secs, flops, launches) = max(agg.items(), key=lambda kv: kv[1][0])
@@ -203,11 +263,10 @@ def main():
             "step_mfma_frac": round(ips * flop_img / (world * PEAK_BF16_TFLOPS * 1e12), 4),
             "roofline": roof, "cpu_baseline": cpu,
         }
-    if world > 1:
+    if world > 1 or args.split:
         dist.barrier()
         dist.destroy_process_group()
-    if rank == 0:
-        print(json.dumps(result))
+    return result if rank == 0 else None
 
 
 if __name__ == "__main__":

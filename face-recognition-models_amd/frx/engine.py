@@ -362,7 +362,21 @@ class ResNet50Engine:
             kw["epi_scale"], kw["epi_shift"] = self._bn(self.bn_scale, c), self._bn(self.bn_shift, c)
         return kw
 
+    SPLIT_BLOCK = LAYERS[0] + LAYERS[1]     # first block of layer3: layers 3+4 hold 94 % of the conv parameters
+
     def backward(self, dfeat):
+        self.backward_upper(dfeat)
+        self.backward_lower()
+
+    def grad_ranges(self):
+        """flat-buffer ranges whose gradients are final after backward_upper() / backward_lower():
+        data-parallel training all-reduces the (large) upper ranges while the lower backward still runs"""
+        cut_w = self.blocks[self.SPLIT_BLOCK].conv1.w_off
+        cut_g = self.blocks[self.SPLIT_BLOCK].conv1.g_off
+        first_g = self.convs[0].g_off
+        return {"upper": [(cut_w, first_g), (cut_g, self.n_params)], "lower": [(0, cut_w), (first_g, cut_g)]}
+
+    def backward_upper(self, dfeat):
         """dfeat [N,512] fp32: gradient of the loss w.r.t. feats.  Accumulates into self.grads.
 
         BatchNorm backward is fused into the convolution backward wherever the conv is 1x1: the dgrad that
@@ -389,8 +403,19 @@ class ResNet50Engine:
         dz3 = self._like(S[gi], c3.y)
         ops.bn_bwd_reduce(dt, rows3, c3.Co, g, c3.y, self._bn(self.bn_mean, c3), self._bn(self.bn_invstd, c3),
                           self.bwd_partial, out=last.out, dz_out=dz3)
-        npart = ops.bn_bwd_partial_rows(rows3, c3.Co)
-        for bi in range(len(self.blocks) - 1, -1, -1):
+        self._bw_state = (gi, ops.bn_bwd_partial_rows(rows3, c3.Co))
+        self._backward_blocks(len(self.blocks) - 1, self.SPLIT_BLOCK)
+
+    def backward_lower(self):
+        self._backward_blocks(self.SPLIT_BLOCK - 1, 0)
+        self._backward_stem()
+
+    def _backward_blocks(self, hi, lo):
+        N, dt = self.N, self.dtype
+        S = self.scratch
+        C3, C2, C1, CD = self.coefs
+        gi, npart = self._bw_state
+        for bi in range(hi, lo - 1, -1):
             b = self.blocks[bi]
             prev = self.blocks[bi - 1] if bi > 0 else None
             x_in = prev.out if prev is not None else self.pool_out
@@ -430,8 +455,15 @@ class ResNet50Engine:
                 npart = ops.conv_dgrad_stat_rows(c1.desc)
             else:
                 ops.conv_dgrad_bn(c1.desc, dz1, c1.wt, gnext, addend=addend, pro_y=c1.y, pro_coef=C1)
-            g, gi = gnext, 1 - gi
+            gi = 1 - gi
+        self._bw_state = (gi, npart)
+
+    def _backward_stem(self):
         # stem: max-pool -> ReLU/BN -> conv weight gradient (no image gradient)
+        N, dt = self.N, self.dtype
+        S = self.scratch
+        gi, _ = self._bw_state
+        g = self._like(S[gi], self.pool_out)
         s = self.stem
         dpost = self._like(S[2], s.y)
         ops.stem_pool_bwd(dt, N, s.Ho, s.Ho, 64, g, self.pool_arg, dpost)
@@ -573,6 +605,23 @@ class FaceEngine:
         ops.head_backward(self.head, self.net.feats, self.head_w(), labels, state_t=self.t, gout=gout,
                           dx=self.dfeat, dw=self.head_w(self.net.grads), accumulate_dw=False)
         self.net.backward(self.dfeat)
+
+    # the same step in three graph-capturable pieces, so data-parallel training can all-reduce the upper
+    # gradient ranges (94 % of the bytes) while the lower half of the backward still runs
+    def step_upper(self, images, labels):
+        self.net.training = True
+        self.net.zero_grad()
+        out = self.forward_loss(images, labels)
+        ops.head_backward(self.head, self.net.feats, self.head_w(), labels, state_t=self.t, dx=self.dfeat,
+                          dw=self.head_w(self.net.grads), accumulate_dw=False)
+        self.net.backward_upper(self.dfeat)
+        return out
+
+    def step_lower(self):
+        self.net.backward_lower()
+
+    def step_update(self, lr=None):
+        self.net.sgd_step(lr, grad_scale=1.0 / self.world)
 
     def train_step(self, images, labels, lr=None):
         """zero_grad -> forward -> CE -> backward -> [all-reduce] -> SGD (model_utils.py:176-187)."""
