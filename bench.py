@@ -241,8 +241,15 @@ def run():
             label, (secs, flops, launches) = max(agg.items(), key=lambda kv: kv[1][0])
             ach = flops / secs / 1e12
             peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+            # HBM bytes per launch of that kernel from the PMC passes of scripts/collect_traffic.sh (rocprofv3 cannot
+            # run inside this process); null until such a summary has been committed under profiles/
+            traffic = None
+            tf = os.path.join(ROOT, "profiles", "traffic_latest.json")
+            if os.path.exists(tf):
+                with open(tf) as fh:
+                    traffic = json.load(fh).get(label, {}).get("hbm_bytes_per_launch")
             roof = {"bound": "mfma", "kernel": label, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": None,
+                    "frac": round(ach / peak, 4), "traffic": traffic,
                     "avg_launch_us": round(secs / launches * 1e6, 2), "launches_per_step": launches // 3,
                     "per_kernel": {k: {"ms_per_step": round(v[0] / 3 * 1e3, 3), "tflops": round(v[1] / v[0] / 1e12, 1),
                                        "launches_per_step": v[2] // 3} for k, v in sorted(agg.items())}}

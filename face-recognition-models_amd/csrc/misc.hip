@@ -50,10 +50,14 @@ __global__ __launch_bounds__(256) void k_weight_prep(int Co, int RS, int Ci, con
 }
 
 // All layers in ONE launch: table [n][8] of int64 = {src offset (floats), Co, RS, Ci, krsc ptr, crsk ptr,
-// first block, unused}; each block owns 1024 consecutive elements of one layer.
+// first block, mode}.  mode 0: a block copies 1024 consecutive elements (no transpose: the stem).
+// mode 1: a block owns one 64(co) x 64(ci) tile of one tap; the CRSK copy goes through an LDS transpose so
+// both copies are written in full 8-byte-per-lane rows (element-wise scattered bf16 stores cost ~10x the
+// HBM write traffic: measured 991 MB per launch for 98 MB of weights).
 template <typename T>
 __global__ __launch_bounds__(256) void k_weight_prep_batched(int n, const int64_t* __restrict__ table,
                                                              const float* __restrict__ master) {
+  __shared__ float tile[64][65];
   int e = 0;
   for (int i = 1; i < n; ++i) e = ((int64_t)blockIdx.x >= table[i * 8 + 6]) ? i : e;   // tables are ~55 entries
   const int64_t* t = table + e * 8;
@@ -61,21 +65,35 @@ __global__ __launch_bounds__(256) void k_weight_prep_batched(int n, const int64_
   const int Co = (int)t[1], RS = (int)t[2], Ci = (int)t[3];
   T* krsc = reinterpret_cast<T*>(t[4]);
   T* crsk = reinterpret_cast<T*>(t[5]);
-  const long total = (long)Co * RS * Ci;
-  const long base = ((long)blockIdx.x - t[6]) * 1024;
+  const long local = (long)blockIdx.x - t[6];
+  if (t[7] == 0) {
+    const long total = (long)Co * RS * Ci;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long i = local * 1024 + threadIdx.x + 256 * k;
+      if (i < total && krsc) krsc[i] = (T)w[i];
+    }
+    return;
+  }
+  const int tci = Ci / 64, tco = Co / 64;
+  const int ci_t = (int)(local % tci), co_t = (int)((local / tci) % tco), rs = (int)(local / ((long)tci * tco));
+  const int r = threadIdx.x >> 4, q = (threadIdx.x & 15) * 4;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const long i = base + threadIdx.x + 256 * k;
-    if (i < total) {
-      const float v = w[i];
-      if (krsc) krsc[i] = (T)v;
-      if (crsk) {
-        const int ci = (int)(i % Ci);
-        const long q = i / Ci;
-        const int rs = (int)(q % RS);
-        const int co = (int)(q / RS);
-        crsk[((long)ci * RS + rs) * Co + co] = (T)v;
-      }
+    const int co = co_t * 64 + r + 16 * k, ci = ci_t * 64 + q;
+    const long idx = ((long)co * RS + rs) * Ci + ci;
+    const float4 v = *reinterpret_cast<const float4*>(w + idx);
+    tile[r + 16 * k][q] = v.x; tile[r + 16 * k][q + 1] = v.y; tile[r + 16 * k][q + 2] = v.z; tile[r + 16 * k][q + 3] = v.w;
+    if (krsc) { krsc[idx] = (T)v.x; krsc[idx + 1] = (T)v.y; krsc[idx + 2] = (T)v.z; krsc[idx + 3] = (T)v.w; }
+  }
+  __syncthreads();
+  if (crsk) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int ci = ci_t * 64 + r + 16 * k, co = co_t * 64 + q;
+      const long idx = ((long)ci * RS + rs) * Co + co;
+      crsk[idx] = (T)tile[q][r + 16 * k]; crsk[idx + 1] = (T)tile[q + 1][r + 16 * k];
+      crsk[idx + 2] = (T)tile[q + 2][r + 16 * k]; crsk[idx + 3] = (T)tile[q + 3][r + 16 * k];
     }
   }
 }

@@ -238,14 +238,14 @@ class ResNet50Engine:
     def _build_prep_table(self):
         rows, blk = [], 0
         for c in self.convs:
-            if c.stem:      # [64][7][8][4] is copied as-is (KRSC with RS*Ci = 224)
-                ent = (c.w_off, 64, 1, 224, c.wk.data_ptr(), 0)
-            else:
-                ent = (c.w_off, c.Co, c.k * c.k, c.Ci, c.wk.data_ptr(), c.wt.data_ptr())
-            rows.append(ent + (blk, 0))
-            blk += (ent[1] * ent[2] * ent[3] + 1023) // 1024
-        rows.append((self.fc_w_off, FEATURE_DIM, 1, 2048, self.fc_wk.data_ptr(), self.fc_wt.data_ptr(), blk, 0))
-        blk += (FEATURE_DIM * 2048 + 1023) // 1024
+            if c.stem:      # [64][7][8][4] is copied as-is (mode 0: 1024 elements per block)
+                rows.append((c.w_off, 64, 1, 224, c.wk.data_ptr(), 0, blk, 0))
+                blk += (64 * 224 + 1023) // 1024
+            else:           # mode 1: one 64x64 (co x ci) tile of one tap per block
+                rows.append((c.w_off, c.Co, c.k * c.k, c.Ci, c.wk.data_ptr(), c.wt.data_ptr(), blk, 1))
+                blk += (c.Co // 64) * (c.Ci // 64) * c.k * c.k
+        rows.append((self.fc_w_off, FEATURE_DIM, 1, 2048, self.fc_wk.data_ptr(), self.fc_wt.data_ptr(), blk, 1))
+        blk += (FEATURE_DIM // 64) * (2048 // 64)
         self._prep_table = torch.tensor(rows, dtype=torch.int64, device=self.device)
         self._prep_blocks = blk
 

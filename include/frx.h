@@ -210,7 +210,8 @@ int frx_sgd_step(int device, frx_stream_t stream, int64_t n, float* p, const flo
 int frx_weight_prep(int device, frx_stream_t stream, int dtype, int Co, int RS, int Ci, const float* master_krsc,
                     void* krsc, void* crsk);
 /* every layer in one launch: table_dev [n][8] int64 = {offset of the layer's KRSC master in `master` (floats), Co, RS,
- * Ci, krsc pointer or 0, crsk pointer or 0, index of the layer's first block, 0}; a block covers 1024 elements */
+ * Ci, krsc pointer or 0, crsk pointer or 0, index of the layer's first block, mode}; mode 0: a block copies 1024
+ * consecutive elements (no CRSK); mode 1: a block owns one 64(co) x 64(ci) tile of one tap (Co, Ci multiples of 64) */
 int frx_weight_prep_batched(int device, frx_stream_t stream, int dtype, int n, const int64_t* table_dev,
                             const float* master, int total_blocks);
 int frx_input_prep(int device, frx_stream_t stream, int dtype, int N, int H, int W, const void* images,
