@@ -189,6 +189,12 @@ static int wgrad_impl(int device, frx_stream_t stream, const frx_conv_desc* d, c
   splits = cdiv(nchunks, a.chunks_per_split);
   a.splits = splits;
   dim3 grid(a.tilesCo * a.tilesCi * taps * splits), block(256);
+  {
+    const size_t esz = d->dtype == FRX_BF16 ? 2 : 4;
+    const size_t xb = (size_t)d->N * a.Hx * a.Wx * (d->stem ? 4 : d->Ci) * esz, yb = (size_t)a.M * d->Co * esz;
+    FRX_CHECK_ARG(xb < 0x80000000ull && yb < 0x80000000ull, "wgrad: tensors must stay below 2 GiB (32-bit buffer offsets)");
+    a.xbytes = (unsigned)xb; a.ybytes = (unsigned)yb;
+  }
   const int wmode = d->stem ? WG_STEM : ((d->R == 1 && d->S == 1 && d->stride == 1) ? WG_POINTWISE : WG_GENERAL);
   return launch_wgrad((hipStream_t)stream, a, d->dtype, bt, wmode, in_scale != nullptr, pro_y != nullptr, (int)grid.x);
 }

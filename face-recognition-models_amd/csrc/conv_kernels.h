@@ -585,6 +585,7 @@ struct WgradArgs {
   int tilesCo, tilesCi;
   int chunks_per_split;   // K-chunks (of KP pixels) per split
   int splits;
+  unsigned xbytes, ybytes;  // sizes of X and dY (dY2) in bytes: buffer-load bounds
 };
 
 // XOR swizzle of the 32-byte slot inside a pixel row so the 8 pixel rows a half-wave touches
@@ -639,14 +640,11 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
   constexpr int RSTEP = 256 / CPR;
   const int co = co0 + ch * VEC, ci = ci0 + ch * VEC;
   const bool cook = co < a.Co, ciok = ci < xch;
-  const T* ycol = dY + (cook ? co : 0);
-  const T* xcol = X + (ciok ? ci : 0);
   float psc[VEC], psh[VEC];
   if constexpr (PRO) {
 #pragma unroll
     for (int j = 0; j < VEC; ++j) { psc[j] = ciok ? a.in_scale[ci + j] : 0.f; psh[j] = ciok ? a.in_shift[ci + j] : 0.f; }
   }
-
   float yal[VEC], ybe[VEC], yga[VEC];          // YPRO: BN-backward coefficients of this thread's output channels
   if constexpr (YPRO) {
 #pragma unroll
@@ -656,42 +654,60 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
       yga[j] = cook ? a.y_coef[2 * a.Co + co + j] : 0.f;
     }
   }
-  const long y2diff = YPRO ? (reinterpret_cast<const T*>(a.dY2) - dY) : 0;
+  // Buffer loads: per-lane byte offset fixed for the whole kernel (dY, pointwise X) plus a SCALAR offset that
+  // walks the pixel axis; rows past M and columns past the tensor fall outside the descriptor and read 0.
+  constexpr unsigned OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dY), 0, a.ybytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcY2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(YPRO ? a.dY2 : a.dY), 0, a.ybytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.X), 0, a.xbytes, 0x00020000);
+  unsigned yvoff[LD], xvoff[LD];
+  int gn[LD], goh[LD], gow[LD];                 // WG_GENERAL / WG_STEM: output pixel of each staged row, walked incrementally
+#pragma unroll
+  for (int i = 0; i < LD; ++i) {
+    const int r = row0 + RSTEP * i;
+    yvoff[i] = cook ? (unsigned)((r * a.Co + co) * (int)sizeof(T)) : OOB;
+    xvoff[i] = ciok ? (unsigned)((r * a.Ci + ci) * (int)sizeof(T)) : OOB;      // pointwise only
+    if constexpr (WMODE != WG_POINTWISE) {
+      const int m = kbeg * KP + r;
+      gn[i] = m / hw;
+      const int rem = m - gn[i] * hw;
+      goh[i] = rem / a.Wo;
+      gow[i] = rem - goh[i] * a.Wo;
+    }
+  }
+  const int step_w = KP % a.Wo, step_h = KP / a.Wo;      // one chunk = KP pixels further along (n, oh, ow)
+
   uint4 ry[PD][LD], rx[PD][LD];
   uint4 ry2[YPRO ? PD : 1][LD];
-  unsigned rmask[PD];     // bit i: dY row valid, bit 8+i: X row valid (zero-filled at commit otherwise)
+  unsigned rmask[PD];     // bit i: dY row is a real pixel (YPRO must not turn padding rows into gam), bit 8+i: X row valid
 
   auto issue_chunk = [&](int kc, auto slot_tag) {
     constexpr int slot = decltype(slot_tag)::value;
     unsigned msk = 0;
+    const int soy = kc * KP * a.Co * (int)sizeof(T);
 #pragma unroll
     for (int i = 0; i < LD; ++i) {
-      const int m = kc * KP + row0 + RSTEP * i;
-      const bool mok = m < a.M;
-      const int mc = mok ? m : 0;
-      ry[slot][i] = *reinterpret_cast<const uint4*>(ycol + (long)mc * a.Co);       // unconditional (clamped) loads
-      if constexpr (YPRO) ry2[slot][i] = *reinterpret_cast<const uint4*>(ycol + (long)mc * a.Co + y2diff);
-      long xoff;
+      ry[slot][i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rsrcY, yvoff[i], soy, 0));
+      if constexpr (YPRO) ry2[slot][i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rsrcY2, yvoff[i], soy, 0));
+      const bool mok = kc * KP + row0 + RSTEP * i < a.M;
       bool xok = mok && ciok;
       if constexpr (WMODE == WG_POINTWISE) {
-        xoff = (long)mc * a.Ci;                                                    // input pixel == output pixel
+        rx[slot][i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rsrcX, xvoff[i], kc * KP * a.Ci * (int)sizeof(T), 0));
       } else {
-        int n = (int)((float)mc * inv_hw);                                         // exact after one correction (m < 2^24)
-        int rem = mc - n * hw;
-        if (rem < 0) { --n; rem += hw; } else if (rem >= hw) { ++n; rem -= hw; }
-        int oh = (int)((float)rem * inv_wo);
-        int ow = rem - oh * a.Wo;
-        if (ow < 0) { --oh; ow += a.Wo; } else if (ow >= a.Wo) { ++oh; ow -= a.Wo; }
+        unsigned voff;
         if constexpr (WMODE == WG_STEM) {
-          xoff = (((long)n * a.Hx + oh * 2 + tr_) * a.Wx + ow * 2) * 4;
+          voff = (unsigned)((((gn[i] * a.Hx + goh[i] * 2 + tr_) * a.Wx + gow[i] * 2) * 4 + ci) * (int)sizeof(T));
         } else {
-          const int hi = oh * a.stride - a.pad + tr_, wi = ow * a.stride - a.pad + ts_;
-          const bool in = (unsigned)hi < (unsigned)a.Hx && (unsigned)wi < (unsigned)a.Wx;
-          xok = xok && in;
-          xoff = in ? (((long)n * a.Hx + hi) * a.Wx + wi) * a.Ci : 0;
+          const int hi = goh[i] * a.stride - a.pad + tr_, wi = gow[i] * a.stride - a.pad + ts_;
+          xok = xok && (unsigned)hi < (unsigned)a.Hx && (unsigned)wi < (unsigned)a.Wx;
+          voff = (unsigned)((((gn[i] * a.Hx + hi) * a.Wx + wi) * a.Ci + ci) * (int)sizeof(T));
         }
+        rx[slot][i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rsrcX, xok ? voff : OOB, 0, 0));
+        // walk this row's pixel to the next chunk
+        gow[i] += step_w; goh[i] += step_h;
+        if (gow[i] >= a.Wo) { gow[i] -= a.Wo; ++goh[i]; }
+        while (goh[i] >= a.Ho) { goh[i] -= a.Ho; ++gn[i]; }
       }
-      rx[slot][i] = *reinterpret_cast<const uint4*>(xcol + xoff);
       msk |= ((mok && cook) ? 1u : 0u) << i;
       msk |= (xok ? 1u : 0u) << (8 + i);
     }
@@ -706,10 +722,14 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
       const int row = row0 + RSTEP * i;
       const int off = row * RB + ((ch * 16) ^ (sizeof(T) == 2 ? tr_swz<RB>(row) : 0));
       uint4 vy = ry[slot][i], vx = rx[slot][i];
-      if constexpr (PRO) vx = bn_relu_vec<T>(vx, psc, psh, a.in_relu);
-      if constexpr (YPRO) vy = affine2_vec<T>(vy, ry2[slot][i], yal, ybe, yga);
-      if (!((rmask[slot] >> i) & 1u)) vy = make_uint4(0, 0, 0, 0);
-      if (!((rmask[slot] >> (8 + i)) & 1u)) vx = make_uint4(0, 0, 0, 0);
+      if constexpr (PRO) {
+        vx = bn_relu_vec<T>(vx, psc, psh, a.in_relu);
+        if (!((rmask[slot] >> (8 + i)) & 1u)) vx = make_uint4(0, 0, 0, 0);   // out-of-range loads are 0 already; f(0) is not
+      }
+      if constexpr (YPRO) {
+        vy = affine2_vec<T>(vy, ry2[slot][i], yal, ybe, yga);
+        if (!((rmask[slot] >> i) & 1u)) vy = make_uint4(0, 0, 0, 0);
+      }
       *reinterpret_cast<uint4*>(Ys + off) = vy;
       *reinterpret_cast<uint4*>(Xs + off) = vx;
     }
