@@ -65,21 +65,29 @@ def cpu_baseline(threads, max_seconds=25.0):
 
 
 def kernel_pass(eng, images, labels, steps=3):
-    """Per-launch HIP-event timing of the GEMM-class kernels over `steps` eager steps."""
+    """Per-launch HIP-event timing of the GEMM-class kernels over `steps` eager steps.  Each launch is bracketed by
+    events on its own stream; a launch's duration is the MINIMUM over the steps (an eager step is host-paced, so a
+    single sample can include a host hiccup between the first event and the launch).  The totals are scaled
+    back to `steps` steps so that per-step figures read naturally."""
     from frx import ops
     eng.train_step(images, labels)
     torch.cuda.synchronize()
-    ops.PROFILER = []
+    per_step = []
     for _ in range(steps):
+        ops.PROFILER = []
         eng.train_step(images, labels)
-    torch.cuda.synchronize()
-    rec, ops.PROFILER = ops.PROFILER, None
+        torch.cuda.synchronize()
+        per_step.append([(label, flops, e0.elapsed_time(e1) * 1e-3, nbytes) for label, flops, e0, e1, nbytes in ops.PROFILER])
+    ops.PROFILER = None
     agg = {}
-    for label, flops, e0, e1 in rec:
-        a = agg.setdefault(label, [0.0, 0.0, 0])
-        a[0] += e0.elapsed_time(e1) * 1e-3
-        a[1] += flops
-        a[2] += 1
+    for calls in zip(*per_step):
+        label, flops, _, nbytes = calls[0]
+        secs = min(c[2] for c in calls)
+        a = agg.setdefault(label, [0.0, 0.0, 0, 0.0])
+        a[0] += secs * steps
+        a[1] += flops * steps
+        a[2] += steps
+        a[3] += nbytes * steps
     return agg
 
 
@@ -238,9 +246,11 @@ def run():
         agg = kernel_pass(eng, images, labels) if world == 1 else {}      # (eng.allreduce is unset: plain single-GPU step)
         roof = None
         if agg:
-            label, (secs, flops, launches) = max(agg.items(), key=lambda kv: kv[1][0])
-            ach = flops / secs / 1e12
+            label, (secs, flops, launches, nbytes) = max(agg.items(), key=lambda kv: kv[1][0])
             peak = PEAK_BF16_TFLOPS if args.dtype == "bf16" else 157.3
+            ach_tf, ach_gbs = flops / secs / 1e12, nbytes / secs / 1e9
+            # roofline model: the kernel's algorithmic intensity against the ridge point decides which roof binds
+            intensity, ridge = flops / nbytes, peak * 1e12 / (PEAK_HBM_GBS * 1e9)
             # HBM bytes per launch of that kernel from the PMC passes of scripts/collect_traffic.sh (rocprofv3 cannot
             # run inside this process); null until such a summary has been committed under profiles/
             traffic = None
@@ -248,11 +258,20 @@ def run():
             if os.path.exists(tf):
                 with open(tf) as fh:
                     traffic = json.load(fh).get(label, {}).get("hbm_bytes_per_launch")
-            roof = {"bound": "mfma", "kernel": label, "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(ach / peak, 4), "traffic": traffic,
-                    "avg_launch_us": round(secs / launches * 1e6, 2), "launches_per_step": launches // 3,
-                    "per_kernel": {k: {"ms_per_step": round(v[0] / 3 * 1e3, 3), "tflops": round(v[1] / v[0] / 1e12, 1),
-                                       "launches_per_step": v[2] // 3} for k, v in sorted(agg.items())}}
+            common = {"kernel": label, "traffic": traffic, "avg_launch_us": round(secs / launches * 1e6, 2),
+                      "launches_per_step": launches // 3, "flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": round(ridge, 1),
+                      "mfma_tflops": round(ach_tf, 2), "mfma_frac": round(ach_tf / peak, 4),
+                      "hbm_gbs": round(ach_gbs, 1), "hbm_frac": round(ach_gbs / PEAK_HBM_GBS, 4),
+                      "algorithmic_bytes_per_launch": round(nbytes / launches), "algorithmic_flops_per_launch": round(flops / launches),
+                      "per_kernel": {k: {"ms_per_step": round(v[0] / 3 * 1e3, 3), "tflops": round(v[1] / v[0] / 1e12, 1),
+                                         "gbs": round(v[3] / v[0] / 1e9, 1), "launches_per_step": v[2] // 3}
+                                     for k, v in sorted(agg.items())}}
+            if intensity < ridge:
+                roof = {"bound": "hbm", "achieved": round(ach_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(ach_gbs / PEAK_HBM_GBS, 4), **common}
+            else:
+                roof = {"bound": "mfma", "achieved": round(ach_tf, 2), "peak": peak, "unit": "TFLOP/s",
+                        "frac": round(ach_tf / peak, 4), **common}
         cpu = None
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (oracle, configs[0]) ...")

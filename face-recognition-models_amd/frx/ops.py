@@ -17,7 +17,7 @@ ARC, COS, SPHERE, CURR = 0, 1, 2, 3
 PROFILER = None
 
 
-def _timed(label, flops, dev_tensor, fn):
+def _timed(label, flops, dev_tensor, fn, nbytes=0):
     if PROFILER is None:
         return fn()
     e0 = torch.cuda.Event(enable_timing=True)
@@ -26,7 +26,7 @@ def _timed(label, flops, dev_tensor, fn):
     e0.record(st)
     r = fn()
     e1.record(st)
-    PROFILER.append((label, flops, e0, e1))
+    PROFILER.append((label, flops, e0, e1, nbytes))
     return r
 
 
@@ -184,6 +184,20 @@ def conv_stat_rows(d):
     return r
 
 
+def _esz(d):
+    return 2 if d.dtype == 1 else 4
+
+
+def conv_bytes(d, n_in=1, n_out=1, wbytes=None):
+    """algorithmic HBM bytes of one conv-class launch: every operand tensor once (a 3x3 conv still reads its
+    input once), n_in tensors of the input-activation size, n_out of the output size, plus the weights"""
+    e = _esz(d)
+    xin = d.N * d.Hi * d.Wi * (4 if d.stem else d.Ci) * e
+    yout = d.N * d.Ho * d.Wo * d.Co * e
+    w = (d.Co * d.R * d.S * d.Ci * e) if wbytes is None else wbytes
+    return n_in * xin + n_out * yout + w
+
+
 def conv_flops(d):
     """algorithmic FLOPs of one conv pass (2 x MACs; the stem counts its real 7x7x3 taps)"""
     k = 147 if d.stem else d.R * d.S * d.Ci
@@ -194,7 +208,8 @@ def conv_fwd(d, x, w, y, in_scale=None, in_shift=None, in_relu=False, bias=None,
     bm, bn = _igemm_tile(d.N * d.Ho * d.Wo, d.Co)
     _timed(f"k_igemm<{_dt_name(d.dtype)},{bm},{bn}>", conv_flops(d), x, lambda: check(
         _lib.lib().frx_conv_fwd(_dev(x), _stream(x), C.byref(d), _p(x), _p(w), _p(in_scale), _p(in_shift),
-                                int(in_relu), _p(bias), _p(y), int(out_f32), _p(stat_partial)), "frx_conv_fwd"))
+                                int(in_relu), _p(bias), _p(y), int(out_f32), _p(stat_partial)), "frx_conv_fwd"),
+        nbytes=conv_bytes(d))
     return y
 
 
@@ -202,7 +217,7 @@ def conv_dgrad(d, dy, w_crsk, dx, addend=None):
     bm, bn = _igemm_tile(d.N * d.Hi * d.Wi, d.Ci)
     _timed(f"k_igemm<{_dt_name(d.dtype)},{bm},{bn}>", conv_flops(d), dy, lambda: check(
         _lib.lib().frx_conv_dgrad(_dev(dy), _stream(dy), C.byref(d), _p(dy), _p(w_crsk), _p(addend), _p(dx)),
-        "frx_conv_dgrad"))
+        "frx_conv_dgrad"), nbytes=conv_bytes(d, n_in=1 + (addend is not None)))
     return dx
 
 
@@ -210,7 +225,8 @@ def conv_wgrad(d, x, dy, dw, in_scale=None, in_shift=None, in_relu=False):
     bt = 64 if (d.Co <= 64 or (32 if d.stem else d.Ci) <= 64) else 128
     _timed(f"k_wgrad<{_dt_name(d.dtype)},{bt}>", conv_flops(d), x, lambda: check(
         _lib.lib().frx_conv_wgrad(_dev(x), _stream(x), C.byref(d), _p(x), _p(in_scale), _p(in_shift),
-                                  int(in_relu), _p(dy), _p(dw)), "frx_conv_wgrad"))
+                                  int(in_relu), _p(dy), _p(dw)), "frx_conv_wgrad"),
+        nbytes=conv_bytes(d, wbytes=dw.numel() * 4))
     return dw
 
 
@@ -230,7 +246,9 @@ def conv_dgrad_bn(d, dz, w_crsk, dx, addend=None, pro_y=None, pro_coef=None, epi
     bm, bn = _igemm_tile(d.N * d.Hi * d.Wi, d.Ci)
     _timed(f"k_igemm<{_dt_name(d.dtype)},{bm},{bn}>", conv_flops(d), dz, lambda: check(
         _lib.lib().frx_conv_dgrad_bn(_dev(dz), _stream(dz), C.byref(d), _p(dz), _p(w_crsk), _p(addend), _p(dx),
-                                     C.byref(f)), "frx_conv_dgrad_bn"))
+                                     C.byref(f)), "frx_conv_dgrad_bn"),
+        nbytes=conv_bytes(d, n_in=1 + (addend is not None) + (epi_y is not None) + (epi_out is not None),
+                          n_out=1 + (pro_y is not None)))
     return dx
 
 
@@ -238,7 +256,8 @@ def conv_wgrad_bn(d, x, dz, pro_y, pro_coef, dw, in_scale=None, in_shift=None, i
     bt = 64 if (d.Co <= 64 or d.Ci <= 64) else 128
     _timed(f"k_wgrad<{_dt_name(d.dtype)},{bt}>", conv_flops(d), x, lambda: check(
         _lib.lib().frx_conv_wgrad_bn(_dev(x), _stream(x), C.byref(d), _p(x), _p(in_scale), _p(in_shift), int(in_relu),
-                                     _p(dz), _p(pro_y), _p(pro_coef), _p(dw)), "frx_conv_wgrad_bn"))
+                                     _p(dz), _p(pro_y), _p(pro_coef), _p(dw)), "frx_conv_wgrad_bn"),
+        nbytes=conv_bytes(d, n_out=2, wbytes=dw.numel() * 4))
     return dw
 
 
