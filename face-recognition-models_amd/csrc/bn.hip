@@ -23,39 +23,53 @@ template <typename T> struct Vec16 {
 // partial [rows][2][C] (sum, sum of squares from the conv epilogue) -> batch mean / biased var,
 // scale = gamma*invstd, shift = beta - mean*scale, running stats (momentum 0.1, unbiased var).
 // Column sums of a [rows][2][C] partial buffer.  The buffer was just written by up to thousands of
-// blocks, so this is latency-bound: 16 channels x 16 row-lanes per block with 4 independent
-// accumulators per lane keeps many loads in flight; fp32 partial runs are short, the total is fp64.
+// blocks, so this is latency-bound: 16 channels x 64 row-lanes per block, each lane with 8 rows (16 loads)
+// in flight; fp32 partial runs are short, the total is fp64.
+constexpr int FIN_THREADS = 1024, FIN_RL = FIN_THREADS / 16;
 __device__ __forceinline__ void partial_colsum(const float* __restrict__ partial, int rows, int C,
                                                double& s, double& q, int& c) {
-  __shared__ double red[2][16][16];
+  __shared__ double red[2][FIN_RL][16];
   const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
   c = blockIdx.x * 16 + cl;
   double a = 0.0, b = 0.0;
   if (c < C) {
-    int r = rl;
-    for (; r + 48 < rows; r += 64) {
-      const float a0 = partial[((long)r * 2 + 0) * C + c], b0 = partial[((long)r * 2 + 1) * C + c];
-      const float a1 = partial[((long)(r + 16) * 2 + 0) * C + c], b1 = partial[((long)(r + 16) * 2 + 1) * C + c];
-      const float a2 = partial[((long)(r + 32) * 2 + 0) * C + c], b2 = partial[((long)(r + 32) * 2 + 1) * C + c];
-      const float a3 = partial[((long)(r + 48) * 2 + 0) * C + c], b3 = partial[((long)(r + 48) * 2 + 1) * C + c];
-      a += (double)((a0 + a1) + (a2 + a3));
-      b += (double)((b0 + b1) + (b2 + b3));
-    }
-    for (; r < rows; r += 16) {
-      a += (double)partial[((long)r * 2 + 0) * C + c];
-      b += (double)partial[((long)r * 2 + 1) * C + c];
+    constexpr int U = 8;
+    for (int r0 = rl; r0 < rows; r0 += U * FIN_RL) {
+      float va[U], vb[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const int r = r0 + u * FIN_RL;
+        const long o = (long)(r < rows ? r : r0) * 2 * C + c;
+        va[u] = partial[o]; vb[u] = partial[o + C];
+      }
+      float fa = 0.f, fb = 0.f;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const bool live = r0 + u * FIN_RL < rows;
+        fa += live ? va[u] : 0.f; fb += live ? vb[u] : 0.f;
+      }
+      a += (double)fa; b += (double)fb;
     }
   }
   red[0][rl][cl] = a; red[1][rl][cl] = b;
   __syncthreads();
+  // 64 row-lanes -> 4 (the first wave: 16 channels x 4 groups of 16 row-lanes) -> 1
+  __shared__ double red2[2][4][16];
+  if (rl < 4) {
+    double ss = 0.0, qq = 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { ss += red[0][rl * 16 + i][cl]; qq += red[1][rl * 16 + i][cl]; }
+    red2[0][rl][cl] = ss; red2[1][rl][cl] = qq;
+  }
+  __syncthreads();
   s = 0.0; q = 0.0;
   if (threadIdx.x < 16) {
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { s += red[0][i][cl]; q += red[1][i][cl]; }
+    for (int i = 0; i < 4; ++i) { s += red2[0][i][cl]; q += red2[1][i][cl]; }
   }
 }
 
-__global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ partial, int rows, int C,
+__global__ __launch_bounds__(FIN_THREADS) void k_bn_finalize(const float* __restrict__ partial, int rows, int C,
                                                      double count, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps, float momentum,
                                                      float* __restrict__ rmean, float* __restrict__ rvar,
@@ -108,6 +122,23 @@ struct RowWalk {
   }
 };
 
+// 8 consecutive per-channel constants as two 16-byte loads (V = 4: one)
+template <int V> __device__ __forceinline__ void load_consts(const float* __restrict__ p, float (&o)[V]) {
+#pragma unroll
+  for (int q = 0; q < V / 4; ++q) {
+    const float4 t = *reinterpret_cast<const float4*>(p + 4 * q);
+    o[4 * q] = t.x; o[4 * q + 1] = t.y; o[4 * q + 2] = t.z; o[4 * q + 3] = t.w;
+  }
+}
+template <int V> __device__ __forceinline__ void fill_consts(float v, float (&o)[V]) {
+#pragma unroll
+  for (int j = 0; j < V; ++j) o[j] = v;
+}
+
+// The row loops below are unrolled RU-fold with every load of the RU rows issued before the first use:
+// one 16-byte load pair per thread in flight leaves these sweeps latency-bound at ~2.6 TB/s.
+constexpr int RU = 4;
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_merge_fwd(long rows, int C, const T* __restrict__ y3,
                                                    const float* __restrict__ s3, const float* __restrict__ b3,
@@ -115,23 +146,30 @@ __global__ __launch_bounds__(256) void k_merge_fwd(long rows, int C, const T* __
                                                    const float* __restrict__ bd, T* __restrict__ out) {
   constexpr int V = Vec16<T>::N;
   const RowWalk w(C, V);
+  const long stride = (long)gridDim.x * w.rpp;
   for (int g0 = 0; g0 < w.groups; g0 += w.gpb) {
     const int grp = g0 + w.tg, c = grp * V;
     float ks[V], kb[V], ds[V], db[V];
+    load_consts<V>(s3 + c, ks); load_consts<V>(b3 + c, kb);
+    if (sd) { load_consts<V>(sd + c, ds); load_consts<V>(bd + c, db); } else { fill_consts<V>(1.f, ds); fill_consts<V>(0.f, db); }
+    for (long r = (long)blockIdx.x * w.rpp + w.trow; r < rows; r += RU * stride) {
+      Vec16<T> a[RU], b[RU];
 #pragma unroll
-    for (int j = 0; j < V; ++j) {
-      ks[j] = s3[c + j]; kb[j] = b3[c + j];
-      ds[j] = sd ? sd[c + j] : 1.f; db[j] = sd ? bd[c + j] : 0.f;
-    }
-    for (long r = (long)blockIdx.x * w.rpp + w.trow; r < rows; r += (long)gridDim.x * w.rpp) {
-      const long i = r * w.groups + grp;
-      Vec16<T> a, b, o;
-      a.raw = reinterpret_cast<const uint4*>(y3)[i];
-      b.raw = reinterpret_cast<const uint4*>(idn)[i];
+      for (int u = 0; u < RU; ++u) {
+        const long rr = r + u * stride;
+        const long i = (rr < rows ? rr : r) * w.groups + grp;      // clamp: loads stay unconditional
+        a[u].raw = reinterpret_cast<const uint4*>(y3)[i];
+        b[u].raw = reinterpret_cast<const uint4*>(idn)[i];
+      }
 #pragma unroll
-      for (int j = 0; j < V; ++j)
-        o.set(j, fmaxf(fmaf(a.get(j), ks[j], kb[j]) + fmaf(b.get(j), ds[j], db[j]), 0.f));
-      reinterpret_cast<uint4*>(out)[i] = o.raw;
+      for (int u = 0; u < RU; ++u) {
+        const long rr = r + u * stride;
+        Vec16<T> o;
+#pragma unroll
+        for (int j = 0; j < V; ++j)
+          o.set(j, fmaxf(fmaf(a[u].get(j), ks[j], kb[j]) + fmaf(b[u].get(j), ds[j], db[j]), 0.f));
+        if (rr < rows) reinterpret_cast<uint4*>(out)[rr * w.groups + grp] = o.raw;
+      }
     }
   }
 }
@@ -158,31 +196,40 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(long rows, int C, const T
     const int grp = g0 + tg;
     const int c = grp * V;
     float s1[V], s2[V], mu[V], is[V], sc[V], sh[V];
-#pragma unroll
-    for (int j = 0; j < V; ++j) {
-      s1[j] = 0.f; s2[j] = 0.f;
-      mu[j] = mean[c + j]; is[j] = invstd[c + j];
-      sc[j] = scale ? scale[c + j] : 1.f; sh[j] = shift ? shift[c + j] : 0.f;
-    }
+    fill_consts<V>(0.f, s1); fill_consts<V>(0.f, s2);
+    load_consts<V>(mean + c, mu); load_consts<V>(invstd + c, is);
+    if (scale) load_consts<V>(scale + c, sc); else fill_consts<V>(1.f, sc);
+    if (shift) load_consts<V>(shift + c, sh); else fill_consts<V>(0.f, sh);
     if (trow < rpp) {
-      for (long r = (long)blockIdx.x * rpp + trow; r < rows; r += (long)gridDim.x * rpp) {
-        const long i = r * groups + grp;
-        Vec16<T> vg, vy, vo, vz;
-        vg.raw = reinterpret_cast<const uint4*>(g)[i];
-        vy.raw = reinterpret_cast<const uint4*>(y)[i];
-        if (out) vo.raw = reinterpret_cast<const uint4*>(out)[i];
+      const long stride = (long)gridDim.x * rpp;
+      for (long r = (long)blockIdx.x * rpp + trow; r < rows; r += RU * stride) {
+        Vec16<T> vg[RU], vy[RU], vo[RU];
 #pragma unroll
-        for (int j = 0; j < V; ++j) {
-          const float yy = vy.get(j);
-          bool on = true;
-          if (out) on = vo.get(j) > 0.f;
-          else if (relu) on = fmaf(yy, sc[j], sh[j]) > 0.f;
-          const float dz = on ? vg.get(j) : 0.f;
-          s1[j] += dz;
-          s2[j] += dz * (yy - mu[j]) * is[j];
-          vz.set(j, dz);
+        for (int u = 0; u < RU; ++u) {
+          const long rr = r + u * stride;
+          const long i = (rr < rows ? rr : r) * groups + grp;
+          vg[u].raw = reinterpret_cast<const uint4*>(g)[i];
+          vy[u].raw = reinterpret_cast<const uint4*>(y)[i];
+          if (out) vo[u].raw = reinterpret_cast<const uint4*>(out)[i];
         }
-        if (dz_out) reinterpret_cast<uint4*>(dz_out)[i] = vz.raw;
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+          const long rr = r + u * stride;
+          const bool live = rr < rows;
+          Vec16<T> vz;
+#pragma unroll
+          for (int j = 0; j < V; ++j) {
+            const float yy = vy[u].get(j);
+            bool on = live;
+            if (out) on = on && vo[u].get(j) > 0.f;
+            else if (relu) on = on && fmaf(yy, sc[j], sh[j]) > 0.f;
+            const float dz = on ? vg[u].get(j) : 0.f;
+            s1[j] += dz;
+            s2[j] += dz * (yy - mu[j]) * is[j];
+            vz.set(j, dz);
+          }
+          if (dz_out && live) reinterpret_cast<uint4*>(dz_out)[rr * groups + grp] = vz.raw;
+        }
       }
     }
     // reduce over the rpp row-lanes that share a channel group
@@ -203,7 +250,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(long rows, int C, const T
 }
 
 // partial [nblk][2][C] -> dgamma += , dbeta += , coef [3][C] = (alpha, beta, gam) with dy = alpha*dz + beta*y + gam
-__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict__ partial, int nblk, int C,
+__global__ __launch_bounds__(FIN_THREADS) void k_bn_bwd_finalize(const float* __restrict__ partial, int nblk, int C,
                                                          double count, const float* __restrict__ gamma,
                                                          const float* __restrict__ mean,
                                                          const float* __restrict__ invstd,
@@ -238,27 +285,34 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(long rows, int C, const T*
   for (int g0 = 0; g0 < w.groups; g0 += w.gpb) {
     const int grp = g0 + w.tg, c = grp * V;
     float al[V], be[V], ga[V], sc[V], sh[V];
+    load_consts<V>(coef + c, al); load_consts<V>(coef + C + c, be); load_consts<V>(coef + 2 * C + c, ga);
+    if (relu && !out) { load_consts<V>(scale + c, sc); load_consts<V>(shift + c, sh); } else { fill_consts<V>(1.f, sc); fill_consts<V>(0.f, sh); }
+    const long stride = (long)gridDim.x * w.rpp;
+    for (long r = (long)blockIdx.x * w.rpp + w.trow; r < rows; r += RU * stride) {
+      Vec16<T> vg[RU], vy[RU], vo[RU];
 #pragma unroll
-    for (int j = 0; j < V; ++j) {
-      al[j] = coef[c + j]; be[j] = coef[C + c + j]; ga[j] = coef[2 * C + c + j];
-      sc[j] = (relu && !out) ? scale[c + j] : 1.f; sh[j] = (relu && !out) ? shift[c + j] : 0.f;
-    }
-    for (long r = (long)blockIdx.x * w.rpp + w.trow; r < rows; r += (long)gridDim.x * w.rpp) {
-      const long i = r * w.groups + grp;
-      Vec16<T> vg, vy, vo, vd;
-      vg.raw = reinterpret_cast<const uint4*>(g)[i];
-      vy.raw = reinterpret_cast<const uint4*>(y)[i];
-      if (out) vo.raw = reinterpret_cast<const uint4*>(out)[i];
-#pragma unroll
-      for (int j = 0; j < V; ++j) {
-        const float yy = vy.get(j);
-        bool on = true;
-        if (out) on = vo.get(j) > 0.f;
-        else if (relu) on = fmaf(yy, sc[j], sh[j]) > 0.f;
-        const float dz = on ? vg.get(j) : 0.f;
-        vd.set(j, fmaf(al[j], dz, fmaf(be[j], yy, ga[j])));
+      for (int u = 0; u < RU; ++u) {
+        const long rr = r + u * stride;
+        const long i = (rr < rows ? rr : r) * w.groups + grp;
+        vg[u].raw = reinterpret_cast<const uint4*>(g)[i];
+        vy[u].raw = reinterpret_cast<const uint4*>(y)[i];
+        if (out) vo[u].raw = reinterpret_cast<const uint4*>(out)[i];
       }
-      reinterpret_cast<uint4*>(dy)[i] = vd.raw;
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        const long rr = r + u * stride;
+        Vec16<T> vd;
+#pragma unroll
+        for (int j = 0; j < V; ++j) {
+          const float yy = vy[u].get(j);
+          bool on = true;
+          if (out) on = vo[u].get(j) > 0.f;
+          else if (relu) on = fmaf(yy, sc[j], sh[j]) > 0.f;
+          const float dz = on ? vg[u].get(j) : 0.f;
+          vd.set(j, fmaf(al[j], dz, fmaf(be[j], yy, ga[j])));
+        }
+        if (rr < rows) reinterpret_cast<uint4*>(dy)[rr * w.groups + grp] = vd.raw;
+      }
     }
   }
 }
@@ -367,11 +421,12 @@ __global__ __launch_bounds__(256) void k_avgpool_bwd(int N, int HW, int C, const
   }
 }
 
-// grid for the RowWalk kernels: enough blocks to cover the rows, capped at 16 per CU
+// grid for the RowWalk kernels: every thread gets RU rows per trip (all their loads in flight together);
+// more blocks than that only re-read clamped rows
 static inline int row_grid(long rows, int C, int V) {
   const int groups = C / V;
   const int rpp = groups < 256 ? 256 / groups : 1;
-  long b = (rows + rpp - 1) / rpp;
+  long b = (rows + (long)rpp * RU - 1) / ((long)rpp * RU);
   if (b > 256 * 16) b = 256 * 16;
   if (b < 1) b = 1;
   return (int)b;
@@ -399,7 +454,7 @@ extern "C" int frx_bn_finalize(int device, frx_stream_t stream, const float* par
   FRX_CHECK_ARG(rows > 0 && C > 0 && count > 0, "bn_finalize: bad sizes");
   FRX_CHECK_ARG((running_mean == nullptr) == (running_var == nullptr), "bn_finalize: running stats come together");
   FRX_ENTER(device);
-  hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, partial, rows, C,
+  hipLaunchKernelGGL(k_bn_finalize, dim3(cdiv(C, 16)), dim3(FIN_THREADS), 0, (hipStream_t)stream, partial, rows, C,
                      (double)count, gamma, beta, eps, momentum, running_mean, running_var, mean, invstd, scale, shift);
   FRX_LAUNCH_CHECK();
   return FRX_OK;
@@ -436,10 +491,13 @@ extern "C" int frx_block_merge_fwd(int device, frx_stream_t stream, int dtype, i
 }
 
 extern "C" int frx_bn_bwd_partial_rows(int64_t rows, int C) {
-  long b = (rows + 31) / 32;
+  // one partial row per block of k_bn_bwd_reduce; a block's threads each take RU rows per trip.  The dtype is
+  // not known here: 8 channels per 16-byte group (bf16) gives the larger count, which fp32 callers over-allocate.
+  const int groups = C >= 8 ? C / 8 : 1;
+  const long rpp = groups < 256 ? 256 / groups : 1;
+  long b = (rows + rpp * RU - 1) / (rpp * RU);
   if (b > 512) b = 512;
   if (b < 1) b = 1;
-  (void)C;
   return (int)b;
 }
 
@@ -471,7 +529,7 @@ extern "C" int frx_bn_bwd_finalize(int device, frx_stream_t stream, const float*
                                    float* dgamma, float* dbeta, float* coef) {
   FRX_CHECK_ARG(partial && gamma && mean && invstd && coef && nblk > 0 && C > 0 && count > 0, "bn_bwd_finalize: bad args");
   FRX_ENTER(device);
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, partial, nblk, C,
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(cdiv(C, 16)), dim3(FIN_THREADS), 0, (hipStream_t)stream, partial, nblk, C,
                      (double)count, gamma, mean, invstd, dgamma, dbeta, coef);
   FRX_LAUNCH_CHECK();
   return FRX_OK;

@@ -18,6 +18,17 @@
 
 namespace frx {
 
+// Debug builds (make EXTRA=-DFRX_DBG_TIMES): thread 0 of every block records four wall-clock stamps (100 MHz)
+// -- start, ring filled, K loop done, epilogue done -- read back by scripts/*_stamps.py.
+#ifdef FRX_DBG_TIMES
+static __device__ long long g_dbg_times[8192 * 4];
+#define FRX_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 8192) g_dbg_times[blockIdx.x * 4 + (k)] = (long long)__builtin_amdgcn_s_memrealtime(); } while (0)
+#define FRX_DBG_EXPORT(name) extern "C" int name(long long* host, int n) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(frx::g_dbg_times), sizeof(long long) * n); }
+#else
+#define FRX_STAMP(k) do {} while (0)
+#define FRX_DBG_EXPORT(name)
+#endif
+
 template <typename T> struct TT;
 template <> struct TT<float>  { static constexpr int VEC = 4, CE = 16; };
 template <> struct TT<bf16_t> { static constexpr int VEC = 8, CE = 32; };
@@ -203,6 +214,7 @@ __global__ __launch_bounds__(256, (PRO == 0 && EPI != EPI_BNBWD_OUT && !ADD) ? 3
   __shared__ __attribute__((aligned(16))) float s_shift[PRO ? PRO_MAXC : 4];
   __shared__ __attribute__((aligned(16))) float s_gam[PRO == 2 ? PRO_MAXC : 4];
 
+  FRX_STAMP(0);
   // XCD-aware tile order: blocks that share an A row-panel (same mt) share an XCD's L2.
   const int bid = blockIdx.x;
   const int xcd = bid & 7, local = bid >> 3;
@@ -404,6 +416,7 @@ __global__ __launch_bounds__(256, (PRO == 0 && EPI != EPI_BNBWD_OUT && !ADD) ? 3
   if (2 < nk) issue_chunk(2, S2{});
   commit_chunk(0, S0{});
   __syncthreads();
+  FRX_STAMP(1);
   // chunk j lives in ring slot j % 3 and in LDS stage j & 1.
   // Steady state: no branch between a load's issue and its wait, so hipcc keeps counted vmcnt(N) waits.
   int kc = 0;
@@ -450,6 +463,7 @@ __global__ __launch_bounds__(256, (PRO == 0 && EPI != EPI_BNBWD_OUT && !ADD) ? 3
   // buffer stores.  The epilogue flavour is a template parameter and every access is a buffer access
   // (rows past M fall outside the descriptor: loads give 0, stores are dropped), so this is
   // straight-line code without per-element predicates; Ncol % BN == 0 is checked on the host.
+  FRX_STAMP(2);
   constexpr bool OUT32 = (EPI == EPI_FC) || sizeof(T) == 4;
   constexpr int OSZ = OUT32 ? 4 : 2;
   const unsigned ybytes = (unsigned)a.M * (unsigned)a.Ncol * OSZ;
@@ -563,6 +577,10 @@ __global__ __launch_bounds__(256, (PRO == 0 && EPI != EPI_BNBWD_OUT && !ADD) ? 3
       a.stat_partial[((long)mt * 2 + which) * a.Ncol + n0 + col] = sum;
     }
   }
+#ifdef FRX_DBG_TIMES
+  __builtin_amdgcn_s_waitcnt(0);
+  FRX_STAMP(3);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------
@@ -602,6 +620,7 @@ enum { WG_POINTWISE = 0, WG_GENERAL = 1, WG_STEM = 2 };
 // is the same for every chunk, so its 8 scale / 8 shift values stay in registers.
 template <typename T, int BT, int WMODE, bool PRO, bool YPRO>   // BT x BT output tile (co x ci)
 __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
+  FRX_STAMP(0);
   constexpr int VEC = TT<T>::VEC;
   constexpr int KP = (sizeof(T) == 2) ? 32 : 16;   // pixels per K-chunk
   constexpr int RB = BT * sizeof(T);               // bytes per pixel row of a tile
@@ -614,12 +633,14 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
 
   // 1-D grid, split index fastest: blocks that stream the SAME pixel range (same split, other
   // tiles / taps) are `splits` apart in dispatch order, i.e. on one XCD when splits % 8 == 0.
-  const int split = blockIdx.x % a.splits;
-  const int rest = blockIdx.x / a.splits;
-  const int tile = rest % (a.tilesCo * a.tilesCi);
-  const int tap = rest / (a.tilesCo * a.tilesCi);
-  const int cot = tile / a.tilesCi, cit = tile % a.tilesCi;
-  const int tr_ = tap / a.S, ts_ = tap % a.S;
+  // (integer division is expanded on the vector ALU: pin the block-uniform results back into SGPRs, or every
+  // buffer load that takes one of them as its scalar offset is wrapped in a waterfall loop)
+  const int split = __builtin_amdgcn_readfirstlane(blockIdx.x % a.splits);
+  const int rest = __builtin_amdgcn_readfirstlane(blockIdx.x / a.splits);
+  const int tile = __builtin_amdgcn_readfirstlane(rest % (a.tilesCo * a.tilesCi));
+  const int tap = __builtin_amdgcn_readfirstlane(rest / (a.tilesCo * a.tilesCi));
+  const int cot = __builtin_amdgcn_readfirstlane(tile / a.tilesCi), cit = tile - cot * a.tilesCi;
+  const int tr_ = __builtin_amdgcn_readfirstlane(tap / a.S), ts_ = tap - tr_ * a.S;
   const int co0 = cot * BT, ci0 = cit * BT;
   const int nchunks = (a.M + KP - 1) / KP;
   const int kbeg = split * a.chunks_per_split;
@@ -803,6 +824,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
   if (2 < nk) issue_chunk(kbeg + 2, S2{});
   commit_chunk(0, S0{});
   __syncthreads();
+  FRX_STAMP(1);
   int j = 0;
   for (; j + 5 < nk; j += 3) {                 // steady state: no branch between issue and wait
     compute_chunk(j & 1);
@@ -839,6 +861,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
     }
   }
 
+  FRX_STAMP(2);
   const int ldw = (WMODE == WG_STEM) ? 32 : a.Ci;   // elements per (co, r, s-row) line of dW
   const bool atomic = a.splits > 1;
 #pragma unroll
@@ -856,6 +879,10 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
         }
       }
     }
+#ifdef FRX_DBG_TIMES
+  __builtin_amdgcn_s_waitcnt(0);
+  FRX_STAMP(3);
+#endif
 }
 
 }  // namespace frx

@@ -15,3 +15,5 @@ int launch_igemm_dgrad_plain(hipStream_t st, const ConvArgs& a, int dtype, TileC
   return FRX_OK;
 }
 }  // namespace frx
+
+FRX_DBG_EXPORT(frx_debug_times_dgrad_plain)

@@ -22,3 +22,5 @@ int launch_igemm_stem(hipStream_t st, const ConvArgs& a, int dtype, TileCfg c, i
   return FRX_OK;
 }
 }  // namespace frx
+
+FRX_DBG_EXPORT(frx_debug_times_fwd)

@@ -19,3 +19,5 @@ int launch_wgrad(hipStream_t st, const WgradArgs& a, int dtype, int bt, int wmod
   return FRX_OK;
 }
 }  // namespace frx
+
+FRX_DBG_EXPORT(frx_debug_times_wgrad)

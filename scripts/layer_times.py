@@ -11,8 +11,8 @@ images = (torch.rand(N, 3, 112, 112, generator=g) * 2 - 1).cuda(); labels = torc
 # wrap to capture descriptors
 calls = []
 orig = ops._timed
-def timed(label, flops, t, fn):
-    calls.append(label); return orig(label, flops, t, fn)
+def timed(label, flops, t, fn, nbytes=0):
+    calls.append(label); return orig(label, flops, t, fn, nbytes)
 ops._timed = timed
 descs = []
 for name in ("conv_fwd", "conv_dgrad", "conv_wgrad", "conv_dgrad_bn", "conv_wgrad_bn"):
@@ -30,14 +30,14 @@ for _ in range(REP):
     descs.clear(); ops.PROFILER = []
     eng.train_step(images, labels, 0.1)
     torch.cuda.synchronize()
-    ts = [e0.elapsed_time(e1) * 1e3 for (_, _, e0, e1) in ops.PROFILER]
+    ts = [r[2].elapsed_time(r[3]) * 1e3 for r in ops.PROFILER]
     acc = ts if acc is None else [min(a, b) for a, b in zip(acc, ts)]
 rec = ops.PROFILER; ops.PROFILER = None
 tot = {}
 print(f"{'op':11s} {'kernel':24s} {'Ci':>5s} {'Co':>5s} k s {'Hi':>3s} {'us':>8s} {'TF/s':>7s} {'GB/s':>7s}")
-for (name, d), (label, flops, _, _), us in zip(descs, rec, acc):
+for (name, d), (label, flops, _, _, nb), us in zip(descs, rec, acc):
     M_out = d.N * d.Ho * d.Wo; M_in = d.N * d.Hi * d.Wi
-    byt = 2 * (M_in * (4 if d.stem else d.Ci) + M_out * d.Co + d.Co * d.R * d.S * d.Ci)
+    byt = nb or 2 * (M_in * (4 if d.stem else d.Ci) + M_out * d.Co + d.Co * d.R * d.S * d.Ci)
     print(f"{name:11s} {label:24s} {d.Ci:5d} {d.Co:5d} {d.R} {d.stride} {d.Hi:3d} {us:8.1f} {flops/us/1e6:7.1f} {byt/us/1e3:7.0f}")
     tot[name] = tot.get(name, 0) + us
 print({k: round(v / 1e3, 3) for k, v in tot.items()}, "ms")
