@@ -661,18 +661,27 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
   constexpr int RSTEP = 256 / CPR;
   const int co = co0 + ch * VEC, ci = ci0 + ch * VEC;
   const bool cook = co < a.Co, ciok = ci < xch;
+  // per-channel constants as 16-byte loads (channel groups past the tensor read group 0: their columns are never stored)
   float psc[VEC], psh[VEC];
   if constexpr (PRO) {
+    const int cs = ciok ? ci : 0;
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) { psc[j] = ciok ? a.in_scale[ci + j] : 0.f; psh[j] = ciok ? a.in_shift[ci + j] : 0.f; }
+    for (int q = 0; q < VEC / 4; ++q) {
+      const float4 s4 = *reinterpret_cast<const float4*>(a.in_scale + cs + 4 * q), h4 = *reinterpret_cast<const float4*>(a.in_shift + cs + 4 * q);
+      psc[4 * q] = s4.x; psc[4 * q + 1] = s4.y; psc[4 * q + 2] = s4.z; psc[4 * q + 3] = s4.w;
+      psh[4 * q] = h4.x; psh[4 * q + 1] = h4.y; psh[4 * q + 2] = h4.z; psh[4 * q + 3] = h4.w;
+    }
   }
   float yal[VEC], ybe[VEC], yga[VEC];          // YPRO: BN-backward coefficients of this thread's output channels
   if constexpr (YPRO) {
+    const int cs = cook ? co : 0;
 #pragma unroll
-    for (int j = 0; j < VEC; ++j) {
-      yal[j] = cook ? a.y_coef[co + j] : 0.f;
-      ybe[j] = cook ? a.y_coef[a.Co + co + j] : 0.f;
-      yga[j] = cook ? a.y_coef[2 * a.Co + co + j] : 0.f;
+    for (int q = 0; q < VEC / 4; ++q) {
+      const float4 a4 = *reinterpret_cast<const float4*>(a.y_coef + cs + 4 * q), b4 = *reinterpret_cast<const float4*>(a.y_coef + a.Co + cs + 4 * q),
+                   g4 = *reinterpret_cast<const float4*>(a.y_coef + 2 * a.Co + cs + 4 * q);
+      yal[4 * q] = a4.x; yal[4 * q + 1] = a4.y; yal[4 * q + 2] = a4.z; yal[4 * q + 3] = a4.w;
+      ybe[4 * q] = b4.x; ybe[4 * q + 1] = b4.y; ybe[4 * q + 2] = b4.z; ybe[4 * q + 3] = b4.w;
+      yga[4 * q] = g4.x; yga[4 * q + 1] = g4.y; yga[4 * q + 2] = g4.z; yga[4 * q + 3] = g4.w;
     }
   }
   // Buffer loads: per-lane byte offset fixed for the whole kernel (dY, pointwise X) plus a SCALAR offset that
@@ -700,7 +709,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
 
   uint4 ry[PD][LD], rx[PD][LD];
   uint4 ry2[YPRO ? PD : 1][LD];
-  unsigned rmask[PD];     // bit i: dY row is a real pixel (YPRO must not turn padding rows into gam), bit 8+i: X row valid
+  unsigned rmask[PD];     // WG_GENERAL / WG_STEM: bit i = the gathered X row of load i is inside the image
 
   auto issue_chunk = [&](int kc, auto slot_tag) {
     constexpr int slot = decltype(slot_tag)::value;
@@ -710,11 +719,10 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
     for (int i = 0; i < LD; ++i) {
       ry[slot][i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rsrcY, yvoff[i], soy, 0));
       if constexpr (YPRO) ry2[slot][i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rsrcY2, yvoff[i], soy, 0));
-      const bool mok = kc * KP + row0 + RSTEP * i < a.M;
-      bool xok = mok && ciok;
       if constexpr (WMODE == WG_POINTWISE) {
         rx[slot][i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rsrcX, xvoff[i], kc * KP * a.Ci * (int)sizeof(T), 0));
       } else {
+        bool xok = ciok && kc * KP + row0 + RSTEP * i < a.M;
         unsigned voff;
         if constexpr (WMODE == WG_STEM) {
           voff = (unsigned)((((gn[i] * a.Hx + goh[i] * 2 + tr_) * a.Wx + gow[i] * 2) * 4 + ci) * (int)sizeof(T));
@@ -728,14 +736,17 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
         gow[i] += step_w; goh[i] += step_h;
         if (gow[i] >= a.Wo) { gow[i] -= a.Wo; ++goh[i]; }
         while (goh[i] >= a.Ho) { goh[i] -= a.Ho; ++gn[i]; }
+        msk |= (xok ? 1u : 0u) << i;
       }
-      msk |= ((mok && cook) ? 1u : 0u) << i;
-      msk |= (xok ? 1u : 0u) << (8 + i);
     }
     rmask[slot] = msk;
   };
-  auto commit_chunk = [&](int buf, auto slot_tag) {
+  // Registers -> LDS.  Rows that are not real pixels load as 0, but a prologue turns 0 into f(0): a product
+  // vanishes when EITHER factor is 0, so one operand is forced back to 0 there -- X wherever its gather can leave
+  // the image (3x3 / stem: every chunk), and for pointwise layers only the chunk that straddles M (TAIL).
+  auto commit_chunk = [&](int buf, auto slot_tag, int kc, auto tail_tag) {
     constexpr int slot = decltype(slot_tag)::value;
+    constexpr bool TAIL = decltype(tail_tag)::value;
     char* Ys = smem + buf * (2 * KP * RB);
     char* Xs = Ys + KP * RB;
 #pragma unroll
@@ -745,11 +756,17 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
       uint4 vy = ry[slot][i], vx = rx[slot][i];
       if constexpr (PRO) {
         vx = bn_relu_vec<T>(vx, psc, psh, a.in_relu);
-        if (!((rmask[slot] >> (8 + i)) & 1u)) vx = make_uint4(0, 0, 0, 0);   // out-of-range loads are 0 already; f(0) is not
+        if constexpr (WMODE != WG_POINTWISE) {
+          if (!((rmask[slot] >> i) & 1u)) vx = make_uint4(0, 0, 0, 0);
+        } else if constexpr (TAIL && !YPRO) {
+          if (kc * KP + row >= a.M) vx = make_uint4(0, 0, 0, 0);
+        }
       }
       if constexpr (YPRO) {
         vy = affine2_vec<T>(vy, ry2[slot][i], yal, ybe, yga);
-        if (!((rmask[slot] >> i) & 1u)) vy = make_uint4(0, 0, 0, 0);
+        if constexpr (TAIL) {
+          if (kc * KP + row >= a.M) vy = make_uint4(0, 0, 0, 0);
+        }
       }
       *reinterpret_cast<uint4*>(Ys + off) = vy;
       *reinterpret_cast<uint4*>(Xs + off) = vx;
@@ -819,44 +836,46 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
   using S2 = std::integral_constant<int, 2>;
   static_assert(PD == 3, "ring written out for 3 slots");
   // chunk j (relative to kbeg) lives in ring slot j % 3 and LDS stage j & 1
+  using STEADY = std::false_type;
+  using TAILC = std::true_type;
   issue_chunk(kbeg, S0{});
   if (1 < nk) issue_chunk(kbeg + 1, S1{});
   if (2 < nk) issue_chunk(kbeg + 2, S2{});
-  commit_chunk(0, S0{});
+  commit_chunk(0, S0{}, kbeg, TAILC{});
   __syncthreads();
   FRX_STAMP(1);
   int j = 0;
   for (; j + 5 < nk; j += 3) {                 // steady state: no branch between issue and wait
     compute_chunk(j & 1);
     issue_chunk(kbeg + j + 3, S0{});
-    commit_chunk((j + 1) & 1, S1{});
+    commit_chunk((j + 1) & 1, S1{}, kbeg + j + 1, STEADY{});
     __syncthreads();
     compute_chunk((j + 1) & 1);
     issue_chunk(kbeg + j + 4, S1{});
-    commit_chunk((j + 2) & 1, S2{});
+    commit_chunk((j + 2) & 1, S2{}, kbeg + j + 2, STEADY{});
     __syncthreads();
     compute_chunk((j + 2) & 1);
     issue_chunk(kbeg + j + 5, S2{});
-    commit_chunk((j + 3) & 1, S0{});
+    commit_chunk((j + 3) & 1, S0{}, kbeg + j + 3, STEADY{});
     __syncthreads();
   }
   for (; j < nk; j += 3) {
     {
       compute_chunk(j & 1);
       if (j + 3 < nk) issue_chunk(kbeg + j + 3, S0{});
-      if (j + 1 < nk) commit_chunk((j + 1) & 1, S1{});
+      if (j + 1 < nk) commit_chunk((j + 1) & 1, S1{}, kbeg + j + 1, TAILC{});
       __syncthreads();
     }
     if (j + 1 < nk) {
       compute_chunk((j + 1) & 1);
       if (j + 4 < nk) issue_chunk(kbeg + j + 4, S1{});
-      if (j + 2 < nk) commit_chunk((j + 2) & 1, S2{});
+      if (j + 2 < nk) commit_chunk((j + 2) & 1, S2{}, kbeg + j + 2, TAILC{});
       __syncthreads();
     }
     if (j + 2 < nk) {
       compute_chunk((j + 2) & 1);
       if (j + 5 < nk) issue_chunk(kbeg + j + 5, S2{});
-      if (j + 3 < nk) commit_chunk((j + 3) & 1, S0{});
+      if (j + 3 < nk) commit_chunk((j + 3) & 1, S0{}, kbeg + j + 3, TAILC{});
       __syncthreads();
     }
   }

@@ -7,10 +7,10 @@ from frx import ops
 N = 256; DEV = "cuda:0"
 SHAPES = [(256, 1024, 1, 1, 7), (1024, 256, 1, 1, 7), (256, 256, 3, 1, 7), (128, 512, 1, 1, 14), (512, 128, 1, 1, 14),
           (128, 128, 3, 1, 14), (512, 2048, 1, 1, 4), (512, 512, 3, 1, 4), (64, 256, 1, 1, 28), (64, 64, 3, 1, 28)]
-CFGS = [("base", {}), ("noatomic", {"FRX_WGRAD_NOATOMIC": "1"}),
-        ("na b1024 c8", {"FRX_WGRAD_NOATOMIC": "1", "FRX_WGRAD_BLOCKS": "1024", "FRX_WGRAD_MINCHUNKS": "8"}),
+CFGS = [("base", {}), 
+        
         ("b1024 c8", {"FRX_WGRAD_BLOCKS": "1024", "FRX_WGRAD_MINCHUNKS": "8"}),
-        ("na b2048 c4", {"FRX_WGRAD_NOATOMIC": "1", "FRX_WGRAD_BLOCKS": "2048", "FRX_WGRAD_MINCHUNKS": "4"}),
+        
         ("b256 c64", {"FRX_WGRAD_BLOCKS": "256", "FRX_WGRAD_MINCHUNKS": "64"})]
 def run(d, fn, reps=20):
     for _ in range(3): fn()
