@@ -120,6 +120,11 @@ static int dgrad_impl(int device, frx_stream_t stream, const frx_conv_desc* d, c
       FRX_CHECK_ARG(d->Co <= 2048, "conv_dgrad_bn: BN prologue supports up to 2048 channels (got %d)", d->Co);
       a.X2 = f->pro_y; a.in_scale = f->pro_coef; a.in_shift = f->pro_coef + d->Co; a.pro_gam = f->pro_coef + 2 * d->Co;
     }
+    if (f->pro_dy_out) {
+      FRX_CHECK_ARG(f->pro_y != nullptr, "conv_dgrad_bn: pro_dy_out needs the BN prologue (pro_y)");
+      FRX_CHECK_ARG(d->R == 1 && d->S == 1, "conv_dgrad_bn: pro_dy_out is for 1x1 convs (each dy element is gathered once)");
+      a.dy_out = f->pro_dy_out;
+    }
     if (f->epi_y) {
       FRX_CHECK_ARG(f->epi_mean && f->epi_invstd && f->epi_partial, "conv_dgrad_bn: epilogue needs mean / invstd / partial");
       FRX_CHECK_ARG(f->epi_out || (f->epi_scale && f->epi_shift), "conv_dgrad_bn: epilogue mask needs epi_out or scale/shift");

@@ -58,6 +58,7 @@ struct ConvArgs {
   // PRO == 2 (dgrad): the gathered operand is the BN backward  alpha*dz + beta*y + gam  of two tensors
   const void* X2;         //   y (raw conv output), same indexing as X (= dz); in_scale = alpha, in_shift = beta
   const float* pro_gam;   //   gam [Kc]
+  void* dy_out;           //   optional (1x1): the transformed operand is also stored here, same indexing as X
   // epi_bnbwd (dgrad): the output is the gradient w.r.t. a post-BN(-ReLU) activation; mask it, write dz and
   // reduce  sum(dz), sum(dz*xhat)  per channel into stat_partial (what frx_bn_bwd_reduce does in a pass of its own)
   int epi_bnbwd;
@@ -261,6 +262,11 @@ __global__ __launch_bounds__(256, (PRO == 0 && EPI != EPI_BNBWD_OUT && !ADD) ? 3
   const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.X), 0, a.xbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrcX2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(PRO == 2 ? a.X2 : a.X), 0, a.xbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, a.wbytes, 0x00020000);
+  // PRO == 2 side output: the first column of tiles stores the transformed operand (dy).  The store is
+  // unconditional (a branch in the K loop would cost the counted waits); every other block gets an EMPTY
+  // descriptor, which drops the stores.
+  const __amdgpu_buffer_rsrc_t rsrcDy = __builtin_amdgcn_make_buffer_rsrc(
+      (PRO == 2 && a.dy_out) ? a.dy_out : const_cast<void*>(a.X), 0, (PRO == 2 && a.dy_out && nt == 0) ? a.xbytes : 0u, 0x00020000);
   constexpr unsigned OOB = 0x80000000u;
   unsigned bvoff[BLD];
 #pragma unroll
@@ -357,6 +363,10 @@ __global__ __launch_bounds__(256, (PRO == 0 && EPI != EPI_BNBWD_OUT && !ADD) ? 3
                            s_gam + rc0[slot] + chunk * VEC);
       if constexpr (PRO != 0) {      // out-of-range loads are already 0; a prologue would turn them into f(0)
         if (!((rmask[slot] >> i) & 1u)) v = make_uint4(0, 0, 0, 0);
+      }
+      if constexpr (PRO == 2) {      // (soffset stays the literal 0: see the note on stores in the epilogue)
+        u32x4_t sv; sv[0] = v.x; sv[1] = v.y; sv[2] = v.z; sv[3] = v.w;
+        __builtin_amdgcn_raw_buffer_store_b128(sv, rsrcDy, avoff[i] + (unsigned)(rc0[slot] * (int)sizeof(T)), 0, 0);
       }
       const int row = srow + 64 * i;
       *reinterpret_cast<uint4*>(As + (row * 4 + (chunk ^ swz64(row))) * 16) = v;

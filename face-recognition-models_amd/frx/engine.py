@@ -168,7 +168,7 @@ class ResNet50Engine:
         max_rows = max(c.stat_rows * c.Co for c in self.convs)
         self.stat_partial = torch.empty(2 * max_rows, device=dev)
         max_act = max(c.y.numel() for c in self.convs)
-        self.scratch = [torch.empty(max_act, dtype=self.tdt, device=dev) for _ in range(5)]
+        self.scratch = [torch.empty(max_act, dtype=self.tdt, device=dev) for _ in range(6)]
         max_bp = max(ops.bn_bwd_partial_rows(c.y.numel() // c.Co, c.Co) * c.Co for c in self.convs)
         max_bp = max([max_bp] + [ops.conv_dgrad_stat_rows(c.desc) * c.Ci for c in self.convs if not c.stem])
         self.bwd_partial = torch.empty(2 * max_bp, device=dev)
@@ -422,11 +422,13 @@ class ResNet50Engine:
             c1, c2, c3, ds = b.conv1, b.conv2, b.conv3, b.down
             dz3 = self._like(S[gi], c3.y)                         # masked block-output gradient (feeds bn3 AND the identity)
             self._finalize_bwd(c3, npart, C3)
-            # conv3 (1x1): consumers read dy3 = affine(dz3, y3) on the fly; the dgrad epilogue handles bn2
-            ops.conv_wgrad_bn(c3.desc, c2.y, dz3, c3.y, C3, self.w_grad(c3), in_scale=self._bn(self.bn_scale, c2),
-                              in_shift=self._bn(self.bn_shift, c2), in_relu=True)
+            # conv3 (1x1): the dgrad evaluates dy3 = affine(dz3, y3) while staging its tiles, keeps a copy for the
+            # weight gradient (one tensor to read there, no prologue) and handles bn2 in its epilogue
             dz2 = self._like(S[4], c2.y)
-            ops.conv_dgrad_bn(c3.desc, dz3, c3.wt, dz2, pro_y=c3.y, pro_coef=C3, **self._epi(c2))
+            dy3 = self._like(S[5], c3.y)
+            ops.conv_dgrad_bn(c3.desc, dz3, c3.wt, dz2, pro_y=c3.y, pro_coef=C3, pro_dy_out=dy3, **self._epi(c2))
+            ops.conv_wgrad(c3.desc, c2.y, dy3, self.w_grad(c3), in_scale=self._bn(self.bn_scale, c2),
+                           in_shift=self._bn(self.bn_shift, c2), in_relu=True)
             self._finalize_bwd(c2, ops.conv_dgrad_stat_rows(c3.desc), C2)
             # conv2 (3x3): materialise dy2 once (9 taps would re-evaluate a prologue 9 times)
             dy2 = self._like(S[3], c2.y)
@@ -437,24 +439,26 @@ class ResNet50Engine:
             dz1 = self._like(S[4], c1.y)
             ops.conv_dgrad_bn(c2.desc, dy2, c2.wt, dz1, **self._epi(c1))
             self._finalize_bwd(c1, ops.conv_dgrad_stat_rows(c2.desc), C1)
-            # conv1 (1x1)
-            ops.conv_wgrad_bn(c1.desc, x_in, dz1, c1.y, C1, self.w_grad(c1))
             addend = dz3
             if ds is not None:
                 rowsd = ds.y.numel() // ds.Co
                 ops.bn_bwd_reduce(dt, rowsd, ds.Co, dz3, ds.y, self._bn(self.bn_mean, ds), self._bn(self.bn_invstd, ds),
                                   self.bwd_partial)
                 self._finalize_bwd(ds, ops.bn_bwd_partial_rows(rowsd, ds.Co), CD)
-                ops.conv_wgrad_bn(ds.desc, x_in, dz3, ds.y, CD, self.w_grad(ds))
                 addend = self._like(S[2], x_in)
-                ops.conv_dgrad_bn(ds.desc, dz3, ds.wt, addend, pro_y=ds.y, pro_coef=CD)
+                dyd = self._like(S[5], ds.y)
+                ops.conv_dgrad_bn(ds.desc, dz3, ds.wt, addend, pro_y=ds.y, pro_coef=CD, pro_dy_out=dyd)
+                ops.conv_wgrad(ds.desc, x_in, dyd, self.w_grad(ds))
+            # conv1 (1x1)
             gnext = self._like(S[1 - gi], x_in)
+            dy1 = self._like(S[5], c1.y)
             if prev is not None:      # epilogue: merge-ReLU mask of the block below + its bn3 reduce
-                ops.conv_dgrad_bn(c1.desc, dz1, c1.wt, gnext, addend=addend, pro_y=c1.y, pro_coef=C1,
+                ops.conv_dgrad_bn(c1.desc, dz1, c1.wt, gnext, addend=addend, pro_y=c1.y, pro_coef=C1, pro_dy_out=dy1,
                                   **self._epi(prev.conv3, out=prev.out))
                 npart = ops.conv_dgrad_stat_rows(c1.desc)
             else:
-                ops.conv_dgrad_bn(c1.desc, dz1, c1.wt, gnext, addend=addend, pro_y=c1.y, pro_coef=C1)
+                ops.conv_dgrad_bn(c1.desc, dz1, c1.wt, gnext, addend=addend, pro_y=c1.y, pro_coef=C1, pro_dy_out=dy1)
+            ops.conv_wgrad(c1.desc, x_in, dy1, self.w_grad(c1))
             gi = 1 - gi
         self._bw_state = (gi, npart)
 

@@ -152,6 +152,9 @@ typedef struct frx_dgrad_fuse {
   const float* epi_mean;
   const float* epi_invstd;
   float* epi_partial;
+  void* pro_dy_out;          /* optional (1x1 convs, with pro_y): the prologue's dy = alpha*dz + beta*y + gam is also stored
+                                here ([N,Ho,Wo,Co], dtype T) by the first column of tiles, so that frx_conv_wgrad can read
+                                dy without re-evaluating the BN backward (and without reading two tensors) */
 } frx_dgrad_fuse;
 int frx_conv_dgrad_stat_rows(const frx_conv_desc* d);
 int frx_conv_dgrad_bn(int device, frx_stream_t stream, const frx_conv_desc* d, const void* dz, const void* w_crsk,

@@ -188,9 +188,13 @@ def test_fused_bn_backward_in_dgrad_wgrad(dtype, shape, merge_mask):
     prow = ops.conv_dgrad_stat_rows(d)
     part = torch.zeros(prow, 2, Ci, device=DEV)
     dz_out = torch.empty_like(dx_ref)
+    dy_side = torch.full_like(dy, float("nan")) if k == 1 else None      # 1x1: the prologue's dy is kept for the wgrad
     ops.conv_dgrad_bn(d, dz, wt, dz_out, addend=add, pro_y=y, pro_coef=coef, epi_y=ey, epi_out=eout, epi_scale=esc,
-                      epi_shift=esh, epi_mean=emu, epi_invstd=eis, epi_partial=part)
+                      epi_shift=esh, epi_mean=emu, epi_invstd=eis, epi_partial=part, pro_dy_out=dy_side)
     _close(dz_out, dz_ref.float().cpu(), dtype, "fused dz")
+    if dy_side is not None:
+        assert torch.isfinite(dy_side.float()).all(), "side output has unwritten elements"
+        _close(dy_side, dy.float().cpu(), dtype, "dy side output")
     s_ref, s = part_ref.sum(0).cpu(), part.sum(0).cpu()
     scale = s_ref.abs().max().item() + 1e-6
     assert (s - s_ref).abs().max().item() < (2e-3 if dtype == 0 else 3e-2) * scale
