@@ -422,13 +422,9 @@ class ResNet50Engine:
             c1, c2, c3, ds = b.conv1, b.conv2, b.conv3, b.down
             dz3 = self._like(S[gi], c3.y)                         # masked block-output gradient (feeds bn3 AND the identity)
             self._finalize_bwd(c3, npart, C3)
-            # conv3 (1x1): the dgrad evaluates dy3 = affine(dz3, y3) while staging its tiles, keeps a copy for the
-            # weight gradient (one tensor to read there, no prologue) and handles bn2 in its epilogue
+            # conv3 (1x1): the dgrad evaluates dy3 = affine(dz3, y3) while staging its tiles and handles bn2 in its epilogue
             dz2 = self._like(S[4], c2.y)
-            dy3 = self._like(S[5], c3.y)
-            ops.conv_dgrad_bn(c3.desc, dz3, c3.wt, dz2, pro_y=c3.y, pro_coef=C3, pro_dy_out=dy3, **self._epi(c2))
-            ops.conv_wgrad(c3.desc, c2.y, dy3, self.w_grad(c3), in_scale=self._bn(self.bn_scale, c2),
-                           in_shift=self._bn(self.bn_shift, c2), in_relu=True)
+            self._bwd_1x1(c3, dz3, C3, c2.y, dz2, S[5], x_bn=c2, **self._epi(c2))
             self._finalize_bwd(c2, ops.conv_dgrad_stat_rows(c3.desc), C2)
             # conv2 (3x3): materialise dy2 once (9 taps would re-evaluate a prologue 9 times)
             dy2 = self._like(S[3], c2.y)
@@ -446,21 +442,31 @@ class ResNet50Engine:
                                   self.bwd_partial)
                 self._finalize_bwd(ds, ops.bn_bwd_partial_rows(rowsd, ds.Co), CD)
                 addend = self._like(S[2], x_in)
-                dyd = self._like(S[5], ds.y)
-                ops.conv_dgrad_bn(ds.desc, dz3, ds.wt, addend, pro_y=ds.y, pro_coef=CD, pro_dy_out=dyd)
-                ops.conv_wgrad(ds.desc, x_in, dyd, self.w_grad(ds))
+                self._bwd_1x1(ds, dz3, CD, x_in, addend, S[5])
             # conv1 (1x1)
             gnext = self._like(S[1 - gi], x_in)
-            dy1 = self._like(S[5], c1.y)
             if prev is not None:      # epilogue: merge-ReLU mask of the block below + its bn3 reduce
-                ops.conv_dgrad_bn(c1.desc, dz1, c1.wt, gnext, addend=addend, pro_y=c1.y, pro_coef=C1, pro_dy_out=dy1,
-                                  **self._epi(prev.conv3, out=prev.out))
+                self._bwd_1x1(c1, dz1, C1, x_in, gnext, S[5], addend=addend, **self._epi(prev.conv3, out=prev.out))
                 npart = ops.conv_dgrad_stat_rows(c1.desc)
             else:
-                ops.conv_dgrad_bn(c1.desc, dz1, c1.wt, gnext, addend=addend, pro_y=c1.y, pro_coef=C1, pro_dy_out=dy1)
-            ops.conv_wgrad(c1.desc, x_in, dy1, self.w_grad(c1))
+                self._bwd_1x1(c1, dz1, C1, x_in, gnext, S[5], addend=addend)
             gi = 1 - gi
         self._bw_state = (gi, npart)
+
+    def _bwd_1x1(self, c, dz, coef, x, dx, dy_buf, x_bn=None, addend=None, **epi):
+        """Input and weight gradient of a 1x1 conv whose BN backward is fused (dy = alpha*dz + beta*y + gam).
+        Where writing dy once is cheaper than evaluating it twice -- narrow dy, or deep layers whose wgrad is
+        ALU-bound -- the dgrad keeps a copy for the wgrad (measured per layer type, scripts/layer_times.py);
+        otherwise both kernels evaluate it on the fly (layer1/2 conv3 and the stride-2 projections are HBM-bound)."""
+        pro = {} if x_bn is None else dict(in_scale=self._bn(self.bn_scale, x_bn), in_shift=self._bn(self.bn_shift, x_bn),
+                                           in_relu=True)
+        if c.Co <= c.Ci or (c.Co >= 1024 and c.desc.stride == 1):
+            dy = self._like(dy_buf, c.y)
+            ops.conv_dgrad_bn(c.desc, dz, c.wt, dx, addend=addend, pro_y=c.y, pro_coef=coef, pro_dy_out=dy, **epi)
+            ops.conv_wgrad(c.desc, x, dy, self.w_grad(c), **pro)
+        else:
+            ops.conv_wgrad_bn(c.desc, x, dz, c.y, coef, self.w_grad(c), **pro)
+            ops.conv_dgrad_bn(c.desc, dz, c.wt, dx, addend=addend, pro_y=c.y, pro_coef=coef, **epi)
 
     def _backward_stem(self):
         # stem: max-pool -> ReLU/BN -> conv weight gradient (no image gradient)
