@@ -120,6 +120,12 @@ static int dgrad_impl(int device, frx_stream_t stream, const frx_conv_desc* d, c
       FRX_CHECK_ARG(d->Co <= 2048, "conv_dgrad_bn: BN prologue supports up to 2048 channels (got %d)", d->Co);
       a.X2 = f->pro_y; a.in_scale = f->pro_coef; a.in_shift = f->pro_coef + d->Co; a.pro_gam = f->pro_coef + 2 * d->Co;
     }
+    if (f->addend_stride == 2) {
+      FRX_CHECK_ARG(addend != nullptr, "conv_dgrad_bn: addend_stride without addend");
+      a.add_stride = 2;
+    } else {
+      FRX_CHECK_ARG(f->addend_stride == 0 || f->addend_stride == 1, "conv_dgrad_bn: addend_stride must be 0, 1 or 2");
+    }
     if (f->pro_dy_out) {
       FRX_CHECK_ARG(f->pro_y != nullptr, "conv_dgrad_bn: pro_dy_out needs the BN prologue (pro_y)");
       FRX_CHECK_ARG(d->R == 1 && d->S == 1, "conv_dgrad_bn: pro_dy_out is for 1x1 convs (each dy element is gathered once)");

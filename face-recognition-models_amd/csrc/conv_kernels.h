@@ -53,6 +53,8 @@ struct ConvArgs {
   int in_relu;            // ... followed by ReLU
   const float* bias;      // optional [Ncol]
   const void* addend;     // optional [M][Ncol] (same dtype as Y unless out_f32): Y = acc + addend
+  int add_stride;         // 2: addend is the COMPACT [N,ceil(Ho/2),ceil(Wo/2),Ncol] gradient of a stride-2 1x1 branch,
+                          //    added at the even pixels only (the other 3/4 of that gradient are zeros nobody stores)
   float* stat_partial;    // optional [tilesM][2][Ncol]: column sums / sums of squares of Y
   int out_f32;            // store Y as fp32 regardless of T
   // PRO == 2 (dgrad): the gathered operand is the BN backward  alpha*dz + beta*y + gam  of two tensors
@@ -478,7 +480,6 @@ __global__ __launch_bounds__(256, (PRO == 0 && EPI != EPI_BNBWD_OUT && !ADD) ? 3
   constexpr int OSZ = OUT32 ? 4 : 2;
   const unsigned ybytes = (unsigned)a.M * (unsigned)a.Ncol * OSZ;
   const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(a.Y, 0, ybytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrcAdd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ADD ? a.addend : a.Y), 0, ybytes, 0x00020000);
   const unsigned ebytes = (unsigned)a.M * (unsigned)a.Ncol * (unsigned)sizeof(T);
   const __amdgpu_buffer_rsrc_t rsrcEy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>((EPI == EPI_BNBWD || EPI == EPI_BNBWD_OUT) ? a.e_y : a.Y), 0, ebytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrcEo = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(EPI == EPI_BNBWD_OUT ? a.e_out : a.Y), 0, ebytes, 0x00020000);
@@ -486,6 +487,25 @@ __global__ __launch_bounds__(256, (PRO == 0 && EPI != EPI_BNBWD_OUT && !ADD) ? 3
   const int ncol0 = n0 + wn * WTN + 8 * fq;                     // first of its 8 channels for pair a2 = 0
   const unsigned elem0 = (unsigned)mrow * (unsigned)a.Ncol + (unsigned)ncol0;   // element index of (mrow, ncol0)
   const unsigned rstep = 16u * (unsigned)a.Ncol;                // elements between fragment rows (scalar)
+  unsigned addvo[ADD ? FM : 1];                                 // byte offset of (row i, ncol0) inside the addend
+  unsigned addbytes = ybytes;
+  if constexpr (ADD) {
+    if (a.add_stride == 2) {
+      const int Hc = (a.Ho + 1) >> 1, Wc = (a.Wo + 1) >> 1, hw = a.Ho * a.Wo;
+      addbytes = (unsigned)a.N * Hc * Wc * a.Ncol * OSZ;
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int m = mrow + 16 * i;
+        const int n = m / hw, rem = m - n * hw, h = rem / a.Wo, w = rem - h * a.Wo;
+        const bool on = m < a.M && !((h | w) & 1);
+        addvo[i] = on ? (unsigned)((((n * Hc + (h >> 1)) * Wc + (w >> 1)) * a.Ncol + ncol0) * OSZ) : 0x80000000u;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < FM; ++i) addvo[i] = (elem0 + (unsigned)i * rstep) * OSZ;
+    }
+  }
+  const __amdgpu_buffer_rsrc_t rsrcAdd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ADD ? a.addend : a.Y), 0, addbytes, 0x00020000);
   constexpr bool STATS = (EPI == EPI_STATS || EPI == EPI_BNBWD || EPI == EPI_BNBWD_OUT);
   float csum[FN][4], csq[FN][4];
 #pragma unroll
@@ -506,7 +526,7 @@ __global__ __launch_bounds__(256, (PRO == 0 && EPI != EPI_BNBWD_OUT && !ADD) ? 3
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       const int so_t = (int)(i * rstep * sizeof(T)), so_o = (int)(i * rstep * OSZ);
-      if constexpr (ADD) buf_load8<OUT32 ? 4 : 2>(rsrcAdd, eoff * OSZ, so_o, av[i]);
+      if constexpr (ADD) buf_load8<OUT32 ? 4 : 2>(rsrcAdd, addvo[i] + 32u * a2 * OSZ, 0, av[i]);
       if constexpr (EPI == EPI_BNBWD || EPI == EPI_BNBWD_OUT) buf_load8<sizeof(T)>(rsrcEy, eoff * (unsigned)sizeof(T), so_t, yv[i]);
       if constexpr (EPI == EPI_BNBWD_OUT) buf_load8<sizeof(T)>(rsrcEo, eoff * (unsigned)sizeof(T), so_t, ov[i]);
     }

@@ -25,8 +25,9 @@ class ConvDesc(C.Structure):
 
 
 class DgradFuse(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("pro_y", "pro_coef", "epi_y", "epi_out", "epi_scale", "epi_shift",
-                                          "epi_mean", "epi_invstd", "epi_partial", "pro_dy_out")]
+    _fields_ = ([(n, C.c_void_p) for n in ("pro_y", "pro_coef", "epi_y", "epi_out", "epi_scale", "epi_shift",
+                                           "epi_mean", "epi_invstd", "epi_partial")]
+                + [("addend_stride", C.c_int32), ("pro_dy_out", C.c_void_p)])
 
 
 def library_path() -> str:

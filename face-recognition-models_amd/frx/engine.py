@@ -38,6 +38,7 @@ class ConvSpec:
     stem: bool = False
     # filled by the engine
     desc: object = None
+    desc_c: object = None    # stride-2 1x1 convs: the same conv as a stride-1 one on the coarse grid (compact dgrad)
     w_off: int = 0       # offset of the fp32 master weight (KRSC) in the flat buffers
     w_numel: int = 0
     g_off: int = 0       # gamma offset;  beta = g_off + Co
@@ -140,6 +141,8 @@ class ResNet50Engine:
                 c.desc = ops.conv_desc(dtype, N, H, H, 3, 64, 7, 7, 2, 3, stem=True)
             else:
                 c.desc = ops.conv_desc(dtype, N, c.Hi, c.Hi, c.Ci, c.Co, c.k, c.k, c.stride, c.k // 2)
+                if c.k == 1 and c.stride == 2:
+                    c.desc_c = ops.conv_desc(dtype, N, c.Ho, c.Ho, c.Ci, c.Co, 1, 1, 1, 0)
             if share is not None:
                 c.wk, c.wt = share.convs[ci_].wk, share.convs[ci_].wt
             elif c.stem:
@@ -435,21 +438,29 @@ class ResNet50Engine:
             dz1 = self._like(S[4], c1.y)
             ops.conv_dgrad_bn(c2.desc, dy2, c2.wt, dz1, **self._epi(c1))
             self._finalize_bwd(c1, ops.conv_dgrad_stat_rows(c2.desc), C1)
-            addend = dz3
+            addend, add_stride = dz3, 0
             if ds is not None:
                 rowsd = ds.y.numel() // ds.Co
                 ops.bn_bwd_reduce(dt, rowsd, ds.Co, dz3, ds.y, self._bn(self.bn_mean, ds), self._bn(self.bn_invstd, ds),
                                   self.bwd_partial)
                 self._finalize_bwd(ds, ops.bn_bwd_partial_rows(rowsd, ds.Co), CD)
-                addend = self._like(S[2], x_in)
+                if ds.desc_c is not None:
+                    # stride-2 projection: only the even pixels of its input gradient are non-zero.  Compute those as a
+                    # stride-1 conv on the coarse grid ([N,Ho,Wo,Ci], a quarter of the rows) and let conv1's dgrad add
+                    # them in place, instead of a full-size GEMM whose gather is 3/4 zeros.
+                    addend = S[2][:N * ds.Ho * ds.Ho * ds.Ci].view(N, ds.Ho, ds.Ho, ds.Ci)
+                    add_stride = 2
+                else:
+                    addend = self._like(S[2], x_in)
                 self._bwd_1x1(ds, dz3, CD, x_in, addend, S[5])
             # conv1 (1x1)
             gnext = self._like(S[1 - gi], x_in)
             if prev is not None:      # epilogue: merge-ReLU mask of the block below + its bn3 reduce
-                self._bwd_1x1(c1, dz1, C1, x_in, gnext, S[5], addend=addend, **self._epi(prev.conv3, out=prev.out))
+                self._bwd_1x1(c1, dz1, C1, x_in, gnext, S[5], addend=addend, addend_stride=add_stride,
+                              **self._epi(prev.conv3, out=prev.out))
                 npart = ops.conv_dgrad_stat_rows(c1.desc)
             else:
-                self._bwd_1x1(c1, dz1, C1, x_in, gnext, S[5], addend=addend)
+                self._bwd_1x1(c1, dz1, C1, x_in, gnext, S[5], addend=addend, addend_stride=add_stride)
             gi = 1 - gi
         self._bw_state = (gi, npart)
 
@@ -460,13 +471,14 @@ class ResNet50Engine:
         otherwise both kernels evaluate it on the fly (layer1/2 conv3 and the stride-2 projections are HBM-bound)."""
         pro = {} if x_bn is None else dict(in_scale=self._bn(self.bn_scale, x_bn), in_shift=self._bn(self.bn_shift, x_bn),
                                            in_relu=True)
+        dd = c.desc_c if c.desc_c is not None else c.desc      # dgrad geometry (compact for stride-2 projections)
         if c.Co <= c.Ci or (c.Co >= 1024 and c.desc.stride == 1):
             dy = self._like(dy_buf, c.y)
-            ops.conv_dgrad_bn(c.desc, dz, c.wt, dx, addend=addend, pro_y=c.y, pro_coef=coef, pro_dy_out=dy, **epi)
+            ops.conv_dgrad_bn(dd, dz, c.wt, dx, addend=addend, pro_y=c.y, pro_coef=coef, pro_dy_out=dy, **epi)
             ops.conv_wgrad(c.desc, x, dy, self.w_grad(c), **pro)
         else:
             ops.conv_wgrad_bn(c.desc, x, dz, c.y, coef, self.w_grad(c), **pro)
-            ops.conv_dgrad_bn(c.desc, dz, c.wt, dx, addend=addend, pro_y=c.y, pro_coef=coef, **epi)
+            ops.conv_dgrad_bn(dd, dz, c.wt, dx, addend=addend, pro_y=c.y, pro_coef=coef, **epi)
 
     def _backward_stem(self):
         # stem: max-pool -> ReLU/BN -> conv weight gradient (no image gradient)

@@ -238,11 +238,12 @@ def conv_dgrad_stat_rows(d):
 
 
 def conv_dgrad_bn(d, dz, w_crsk, dx, addend=None, pro_y=None, pro_coef=None, epi_y=None, epi_out=None, epi_scale=None,
-                  epi_shift=None, epi_mean=None, epi_invstd=None, epi_partial=None, pro_dy_out=None):
+                  epi_shift=None, epi_mean=None, epi_invstd=None, epi_partial=None, pro_dy_out=None, addend_stride=0):
     """dgrad with the BatchNorm backward fused in (prologue: dy = alpha*dz + beta*pro_y + gam; epilogue: mask +
     per-channel reduce of the produced gradient)."""
     f = _lib.DgradFuse(*[0 if t is None else t.data_ptr() for t in
-                         (pro_y, pro_coef, epi_y, epi_out, epi_scale, epi_shift, epi_mean, epi_invstd, epi_partial, pro_dy_out)])
+                         (pro_y, pro_coef, epi_y, epi_out, epi_scale, epi_shift, epi_mean, epi_invstd, epi_partial)],
+                       int(addend_stride), 0 if pro_dy_out is None else pro_dy_out.data_ptr())
     bm, bn = _igemm_tile(d.N * d.Hi * d.Wi, d.Ci)
     _timed(f"k_igemm<{_dt_name(d.dtype)},{bm},{bn}>", conv_flops(d), dz, lambda: check(
         _lib.lib().frx_conv_dgrad_bn(_dev(dz), _stream(dz), C.byref(d), _p(dz), _p(w_crsk), _p(addend), _p(dx),

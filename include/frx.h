@@ -152,6 +152,9 @@ typedef struct frx_dgrad_fuse {
   const float* epi_mean;
   const float* epi_invstd;
   float* epi_partial;
+  int32_t addend_stride;     /* 0 / 1: `addend` has dx's shape.  2: it is the COMPACT [N,ceil(Hi/2),ceil(Wi/2),Ci] input
+                                gradient of a stride-2 1x1 branch (computed as a stride-1 conv on the coarse grid) and is
+                                added at the even pixels: the zeros of the other three quarters are never materialised */
   void* pro_dy_out;          /* optional (1x1 convs, with pro_y): the prologue's dy = alpha*dz + beta*y + gam is also stored
                                 here ([N,Ho,Wo,Co], dtype T) by the first column of tiles, so that frx_conv_wgrad can read
                                 dy without re-evaluating the BN backward (and without reading two tensors) */

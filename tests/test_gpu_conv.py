@@ -234,3 +234,29 @@ def test_conv_many_coresident_blocks(dtype, shape):
             assert bad == 0, f"stats={stats} pro={pro}: {bad} corrupted outputs"
             if stats:
                 _close(part[:, 0].sum(0), y.float().cpu().sum((0, 1, 2)), 0, "stat sum")
+
+
+@pytest.mark.parametrize("dtype", [0, 1], ids=["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(256, 128, 28), (512, 256, 14), (64, 64, 9)], ids=lambda s: f"{s[0]}x{s[1]}h{s[2]}")
+def test_dgrad_compact_stride2_addend(dtype, shape):
+    """addend_stride = 2: the compact [N,ceil(H/2),ceil(W/2),Ci] gradient of a stride-2 1x1 branch is added at the even
+    pixels -- identical to adding its zero-filled full-size form (odd H covers the ceil)."""
+    from frx import ops
+    Ci, Co, Hi = shape
+    N = 3
+    d = ops.conv_desc(dtype, N, Hi, Hi, Ci, Co, 1, 1, 1, 0)
+    T = ops.TORCH_DT[dtype]
+    dz = _mk(dtype, N, Hi, Hi, Co, seed=1).to(DEV)
+    y = _mk(dtype, N, Hi, Hi, Co, seed=2).to(DEV)
+    g = torch.Generator().manual_seed(3)
+    coef = torch.cat([torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g) * 0.2, torch.randn(Co, generator=g) * 0.1]).to(DEV)
+    wt = _mk(dtype, Ci, 1, 1, Co, scale=Co ** -0.5, seed=4).to(DEV)
+    Hc = (Hi + 1) // 2
+    compact = _mk(dtype, N, Hc, Hc, Ci, seed=5).to(DEV)
+    full = torch.zeros(N, Hi, Hi, Ci, dtype=T, device=DEV)
+    full[:, ::2, ::2, :] = compact
+    ref = torch.empty(N, Hi, Hi, Ci, dtype=T, device=DEV)
+    ops.conv_dgrad_bn(d, dz, wt, ref, addend=full, pro_y=y, pro_coef=coef)
+    out = torch.empty_like(ref)
+    ops.conv_dgrad_bn(d, dz, wt, out, addend=compact, pro_y=y, pro_coef=coef, addend_stride=2)
+    assert torch.equal(out, ref)
