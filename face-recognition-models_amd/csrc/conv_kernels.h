@@ -139,7 +139,8 @@ __device__ __forceinline__ uint4 bn_relu_vec(uint4 raw, const float* __restrict_
     const float4 b = *reinterpret_cast<const float4*>(sh);
     float4 v = *reinterpret_cast<float4*>(&raw);
     v.x = fmaf(v.x, s.x, b.x); v.y = fmaf(v.y, s.y, b.y); v.z = fmaf(v.z, s.z, b.z); v.w = fmaf(v.w, s.w, b.w);
-    if (relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
+    const float lo = relu ? 0.f : -INFINITY;      // (no per-element select on the flag)
+    v.x = fmaxf(v.x, lo); v.y = fmaxf(v.y, lo); v.z = fmaxf(v.z, lo); v.w = fmaxf(v.w, lo);
     return *reinterpret_cast<uint4*>(&v);
   } else {
     bf16x8 v = *reinterpret_cast<bf16x8*>(&raw);
@@ -149,12 +150,21 @@ __device__ __forceinline__ uint4 bn_relu_vec(uint4 raw, const float* __restrict_
     const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
     bf16x8 o;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      float f = fmaf((float)v[j], ss[j], bb[j]);
-      if (relu) f = fmaxf(f, 0.f);
-      o[j] = (bf16_t)f;
+    for (int j = 0; j < 8; ++j) o[j] = (bf16_t)fmaf((float)v[j], ss[j], bb[j]);
+    // ReLU on the PACKED result: a bf16 is negative exactly when its bit pattern is a negative int16, so one
+    // v_pk_max_i16 against 0 clamps two elements (against INT16_MIN it is the identity: no select on `relu`).
+    typedef short s16x2_t __attribute__((ext_vector_type(2)));
+    const short thr = relu ? (short)0 : (short)-32768;
+    const s16x2_t t2 = {thr, thr};
+    uint4 r = *reinterpret_cast<uint4*>(&o);
+    unsigned* rw = reinterpret_cast<unsigned*>(&r);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      s16x2_t x = *reinterpret_cast<s16x2_t*>(&rw[q]);
+      x = __builtin_elementwise_max(x, t2);
+      rw[q] = *reinterpret_cast<unsigned*>(&x);
     }
-    return *reinterpret_cast<uint4*>(&o);
+    return r;
   }
 }
 
