@@ -745,7 +745,9 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
       gow[i] = rem - goh[i] * a.Wo;
     }
   }
-  const int step_w = KP % a.Wo, step_h = KP / a.Wo;      // one chunk = KP pixels further along (n, oh, ow)
+  // one chunk = KP pixels further along (n, oh, ow): a mixed-radix add with single carries (branch-free -- a
+  // `while` here put two divergent loops into every K-chunk of the 3x3 layers)
+  const int step_n = KP / hw, step_h = (KP % hw) / a.Wo, step_w = (KP % hw) % a.Wo;
 
   uint4 ry[PD][LD], rx[PD][LD];
   uint4 ry2[YPRO ? PD : 1][LD];
@@ -773,9 +775,13 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
         }
         rx[slot][i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rsrcX, xok ? voff : OOB, 0, 0));
         // walk this row's pixel to the next chunk
-        gow[i] += step_w; goh[i] += step_h;
-        if (gow[i] >= a.Wo) { gow[i] -= a.Wo; ++goh[i]; }
-        while (goh[i] >= a.Ho) { goh[i] -= a.Ho; ++gn[i]; }
+        gow[i] += step_w;
+        const int cw = gow[i] >= a.Wo ? 1 : 0;
+        gow[i] -= cw ? a.Wo : 0;
+        goh[i] += step_h + cw;
+        const int chh = goh[i] >= a.Ho ? 1 : 0;
+        goh[i] -= chh ? a.Ho : 0;
+        gn[i] += step_n + chh;
         msk |= (xok ? 1u : 0u) << i;
       }
     }
@@ -886,18 +892,23 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
   FRX_STAMP(1);
   int j = 0;
   for (; j + 5 < nk; j += 3) {                 // steady state: no branch between issue and wait
+    // (sched_barrier: register-only work may otherwise be hoisted across s_barrier -- hipcc moved the unpacking of
+    // the NEWEST ring slot to the top of the iteration, i.e. a vmcnt(0) that drains the ring every three chunks)
     compute_chunk(j & 1);
     issue_chunk(kbeg + j + 3, S0{});
     commit_chunk((j + 1) & 1, S1{}, kbeg + j + 1, STEADY{});
     __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
     compute_chunk((j + 1) & 1);
     issue_chunk(kbeg + j + 4, S1{});
     commit_chunk((j + 2) & 1, S2{}, kbeg + j + 2, STEADY{});
     __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
     compute_chunk((j + 2) & 1);
     issue_chunk(kbeg + j + 5, S2{});
     commit_chunk((j + 3) & 1, S0{}, kbeg + j + 3, STEADY{});
     __syncthreads();
+    __builtin_amdgcn_sched_barrier(0);
   }
   for (; j < nk; j += 3) {
     {
