@@ -2,17 +2,24 @@
 // in several .hip files so that `make -j` compiles them in parallel).
 #pragma once
 #include "conv_kernels.h"
+#include <stdlib.h>
 
 namespace frx {
 
 struct TileCfg { int bm, bn; };
 
 static inline TileCfg pick_tile(long M, int Ncol) {
+  if (const char* e = getenv("FRX_IGEMM_TILE")) {           // tuning aid: "128x128" | "128x64" | "64x64"
+    if (e[0] == '6') return {64, 64};
+    if (e[0] == '1' && e[4] == '6') return {128, 64};
+    if (e[0] == '1' && Ncol % 128 == 0) return {128, 128};
+  }
   if (Ncol <= 64) return {128, 64};
+  // measured per ResNet-50 shape (scripts/tile_sweep.py): the square 128x128 tile wins down to ~3/4 of a wave of
+  // blocks (twice the MFMA work per staged byte and per prologue evaluation); below that the 64x64 tile's 4x
+  // block count beats the 128x64 one's 2x.
   const long mt128 = (M + 127) / 128;
-  if (mt128 * ((Ncol + 127) / 128) >= 384) return {128, 128};
-  // small problems: keep the 256 CUs busy, but prefer the taller tile (more MFMA per LDS byte)
-  if (mt128 * ((Ncol + 63) / 64) >= 256) return {128, 64};
+  if (mt128 * ((Ncol + 127) / 128) >= 192) return {128, 128};
   return {64, 64};
 }
 

@@ -35,10 +35,8 @@ def _igemm_tile(M, ncol):
     if ncol <= 64:
         return 128, 64
     mt = (M + 127) // 128
-    if mt * ((ncol + 127) // 128) >= 384:
+    if mt * ((ncol + 127) // 128) >= 192:
         return 128, 128
-    if mt * ((ncol + 63) // 64) >= 256:
-        return 128, 64
     return 64, 64
 
 
