@@ -356,7 +356,12 @@ __global__ __launch_bounds__(256) void k_pool_fwd(int N, int H, int W, int C, co
       }
     Vec16<T> o;
 #pragma unroll
-    for (int j = 0; j < V; ++j) { o.set(j, best[j]); argmax[i * V + j] = (uint8_t)arg[j]; }
+    for (int j = 0; j < V; ++j) o.set(j, best[j]);
+    uint8_t am[V];
+#pragma unroll
+    for (int j = 0; j < V; ++j) am[j] = (uint8_t)arg[j];
+    if constexpr (V == 8) *reinterpret_cast<uint2*>(argmax + i * V) = *reinterpret_cast<uint2*>(am);
+    else *reinterpret_cast<uint32_t*>(argmax + i * V) = *reinterpret_cast<uint32_t*>(am);
     reinterpret_cast<uint4*>(out)[i] = o.raw;
   }
 }
@@ -386,7 +391,10 @@ __global__ __launch_bounds__(256) void k_pool_bwd(int N, int H, int W, int C, co
         const long o = ((((long)n * Ho + oh) * Wo + ow) * G + g);
         Vec16<T> d;
         d.raw = reinterpret_cast<const uint4*>(dout)[o];
-        const uint8_t* am = argmax + o * V;
+        // the V window codes of this group as ONE load (byte loads were the bulk of this kernel's memory ops)
+        uint8_t am[V];
+        if constexpr (V == 8) *reinterpret_cast<uint2*>(am) = *reinterpret_cast<const uint2*>(argmax + o * V);
+        else *reinterpret_cast<uint32_t*>(am) = *reinterpret_cast<const uint32_t*>(argmax + o * V);
 #pragma unroll
         for (int j = 0; j < V; ++j) if (am[j] == code) acc[j] += d.get(j);
       }

@@ -942,7 +942,10 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int co = co0 + wr * WT + i * 16 + fq * 4 + r;
-        if (co < a.Co && ci < ldw) {
+        // stem: the 8th tap and the 4th channel of the [7][8][4] layout are padding pinned to zero -- leave
+        // their gradient slots alone (they stay 0 from zero_grad) instead of zeroing them after the fact
+        const bool live = (WMODE != WG_STEM) || ((ci >> 2) < 7 && (ci & 3) < 3);
+        if (co < a.Co && ci < ldw && live) {
           const long o = (WMODE == WG_STEM) ? (((long)co * a.R + tr_) * 32 + ci)
                                 : ((((long)co * a.R + tr_) * a.S + ts_) * a.Ci + ci);
           if (atomic) atomicAdd(a.dW + o, acc[i][j][r]); else a.dW[o] += acc[i][j][r];

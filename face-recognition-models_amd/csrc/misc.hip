@@ -150,13 +150,30 @@ __global__ __launch_bounds__(256) void k_cast_to_f32(long n, const T* __restrict
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = (float)x[i];
 }
 
-// out[c] += sum_r x[r][c]   (fc bias gradient)
+// out[c] += sum_r x[r][c]   (fc bias gradient).  16 columns x 16 row-lanes per block, 8 independent loads per
+// lane in flight (a single thread walking 256 rows is 256 dependent memory round trips: 52 us for 0.5 MB).
 __global__ __launch_bounds__(256) void k_colsum_f32(int rows, int C, const float* __restrict__ x, float* __restrict__ out) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float red[16][17];
+  const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   float s = 0.f;
-  for (int r = 0; r < rows; ++r) s += x[(long)r * C + c];
-  out[c] += s;
+  if (c < C) {
+    for (int r0 = rl; r0 < rows; r0 += 16 * 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { const int r = r0 + 16 * u; v[u] = r < rows ? x[(long)r * C + c] : 0.f; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+  }
+  red[rl][cl] = s;
+  __syncthreads();
+  if (threadIdx.x < 16 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t += red[i][cl];
+    out[c] += t;
+  }
 }
 
 static inline int ew_grid2(long n) {
@@ -238,7 +255,7 @@ extern "C" int frx_cast(int device, frx_stream_t stream, int dtype, int to_f32, 
 extern "C" int frx_colsum_f32(int device, frx_stream_t stream, int rows, int C, const float* x, float* out) {
   FRX_CHECK_ARG(x && out && rows > 0 && C > 0, "colsum: bad args");
   FRX_ENTER(device);
-  hipLaunchKernelGGL(k_colsum_f32, dim3(cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, rows, C, x, out);
+  hipLaunchKernelGGL(k_colsum_f32, dim3(cdiv(C, 16)), dim3(256), 0, (hipStream_t)stream, rows, C, x, out);
   FRX_LAUNCH_CHECK();
   return FRX_OK;
 }

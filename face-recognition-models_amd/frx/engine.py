@@ -491,10 +491,7 @@ class ResNet50Engine:
         ops.stem_pool_bwd(dt, N, s.Ho, s.Ho, 64, g, self.pool_arg, dpost)
         dy0 = self._like(S[3], s.y)
         self._bn_backward(s, dpost, dy0, relu=True)
-        ops.conv_wgrad(s.desc, self.xin, dy0, self.w_grad(s))
-        wg = self.w_grad(s)
-        wg[:, :, 7, :] = 0
-        wg[..., 3] = 0
+        ops.conv_wgrad(s.desc, self.xin, dy0, self.w_grad(s))     # (padding tap / channel slots are not written)
 
     # ------------------------------------------------------------------ optimiser
     def zero_grad(self):

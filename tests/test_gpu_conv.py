@@ -124,6 +124,7 @@ def test_stem(dtype):
     ops.conv_wgrad(d, xin, dy.to(DEV), dw)
     refdw = torch.nn.grad.conv2d_weight(imgq, (64, 3, 7, 7), dy.float().permute(0, 3, 1, 2), stride=2, padding=3)
     _close(dw[:, :, :7, :3], refdw.permute(0, 2, 3, 1), dtype, "stem wgrad")
+    assert dw[:, :, 7, :].abs().max().item() == 0 and dw[..., 3].abs().max().item() == 0, "padding slots must stay untouched"
 
 
 @pytest.mark.parametrize("dtype", [0, 1], ids=["f32", "bf16"])
