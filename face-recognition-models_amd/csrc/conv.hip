@@ -4,6 +4,7 @@
 // (main_code/utils/criterion.py:320, model_utils.py:177,185).
 #include "conv_launch.h"
 #include <stdlib.h>
+#include <vector>
 
 namespace frx {
 
@@ -159,55 +160,135 @@ extern "C" int frx_conv_dgrad_stat_rows(const frx_conv_desc* d) {
   return cdiv(M, pick_tile(M, d->Ci).bm);
 }
 
-static int wgrad_impl(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x,
-                      const float* in_scale, const float* in_shift, int in_relu, const void* dy,
-                      const void* pro_y, const float* pro_coef, float* dw) {
+// Geometry shared by the per-layer and the grouped launches; the pixel split is the caller's policy.
+struct WgradGeom { int bt, wmode, taps, nchunks, tiles; };
+static int wgrad_args(const frx_conv_desc* d, const void* x, const float* in_scale, const float* in_shift, int in_relu,
+                      const void* dy, const void* pro_y, const float* pro_coef, float* dw, WgradArgs& a, WgradGeom& g) {
   if (int rc = check_conv(d)) return rc;
   FRX_CHECK_ARG(x && dy && dw, "conv_wgrad: NULL pointer");
   FRX_CHECK_ARG(!(d->stem && in_scale), "conv_wgrad: the stem takes the raw image (no prologue)");
-  FRX_ENTER(device);
-  WgradArgs a{};
+  FRX_CHECK_ARG((pro_y == nullptr) == (pro_coef == nullptr), "conv_wgrad: pro_y / pro_coef come together");
+  a = WgradArgs{};
   a.X = x; a.dY = dy; a.dW = dw;
   a.in_scale = in_scale; a.in_shift = in_shift; a.in_relu = in_relu;
   a.dY2 = pro_y; a.y_coef = pro_coef;
   a.N = d->N; a.Ci = d->Ci; a.Ho = d->Ho; a.Wo = d->Wo; a.Co = d->Co; a.R = d->R; a.S = d->S;
   a.stride = d->stride; a.pad = d->pad; a.M = d->N * d->Ho * d->Wo; a.stem = d->stem;
-  int taps = d->R * d->S;
+  g.taps = d->R * d->S;
   int ci_extent = d->Ci;
   if (d->stem) {
     int hp, wp;
     frx_stem_padded_dims(d->Hi, d->Wi, &hp, &wp);
-    a.Hx = hp; a.Wx = wp; a.S = 1; taps = d->R; ci_extent = 32;
+    a.Hx = hp; a.Wx = wp; a.S = 1; g.taps = d->R; ci_extent = 32;
   } else {
     a.Hx = d->Hi; a.Wx = d->Wi;
   }
   const int kp = d->dtype == FRX_BF16 ? 32 : 16;
-  const int bt = (d->Co <= 64 || ci_extent <= 64) ? 64 : 128;
-  a.tilesCo = cdiv(d->Co, bt);
-  a.tilesCi = cdiv(ci_extent, bt);
-  const int nchunks = cdiv(a.M, kp);
-  const int tiles = a.tilesCo * a.tilesCi * taps;
-  // Split the pixel axis so ~3 blocks per CU exist, but keep >= 16 K-chunks per block (below that
+  g.bt = (d->Co <= 64 || ci_extent <= 64) ? 64 : 128;
+  a.tilesCo = cdiv(d->Co, g.bt);
+  a.tilesCi = cdiv(ci_extent, g.bt);
+  g.nchunks = cdiv(a.M, kp);
+  g.tiles = a.tilesCo * a.tilesCi * g.taps;
+  const size_t esz = d->dtype == FRX_BF16 ? 2 : 4;
+  const size_t xb = (size_t)d->N * a.Hx * a.Wx * (d->stem ? 4 : d->Ci) * esz, yb = (size_t)a.M * d->Co * esz;
+  FRX_CHECK_ARG(xb < 0x80000000ull && yb < 0x80000000ull, "wgrad: tensors must stay below 2 GiB (32-bit buffer offsets)");
+  a.xbytes = (unsigned)xb; a.ybytes = (unsigned)yb;
+  g.wmode = d->stem ? WG_STEM : ((d->R == 1 && d->S == 1 && d->stride == 1) ? WG_POINTWISE : WG_GENERAL);
+  FRX_CHECK_ARG(!(pro_y && g.wmode != WG_POINTWISE && !(d->R == 1 && d->S == 1)), "conv_wgrad_bn: 1x1 convs only");
+  a.variant = (g.bt == 128 ? WGV_BT128 : 0) | (g.wmode == WG_GENERAL ? WGV_GENERAL : 0) | (g.wmode == WG_STEM ? WGV_STEM : 0) |
+              (in_scale ? WGV_PRO : 0) | (pro_y ? WGV_YPRO : 0);
+  return FRX_OK;
+}
+
+static int wgrad_impl(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x,
+                      const float* in_scale, const float* in_shift, int in_relu, const void* dy,
+                      const void* pro_y, const float* pro_coef, float* dw) {
+  WgradArgs a; WgradGeom g;
+  if (int rc = wgrad_args(d, x, in_scale, in_shift, in_relu, dy, pro_y, pro_coef, dw, a, g)) return rc;
+  FRX_ENTER(device);
+  // Split the pixel axis so ~2 blocks per CU exist, but keep >= 32 K-chunks per block (below that
   // the 64-atomics-per-lane epilogue dominates); round to a multiple of 8 for the XCD mapping.
   const char* env_b = getenv("FRX_WGRAD_BLOCKS");
   const char* env_c = getenv("FRX_WGRAD_MINCHUNKS");
   const int target_blocks = env_b ? atoi(env_b) : 512, min_chunks = env_c ? atoi(env_c) : 32;   // measured sweep (atomics vs occupancy)
-  int splits = cdiv(target_blocks, tiles);
-  if (splits > nchunks / min_chunks) splits = nchunks / min_chunks;
+  int splits = cdiv(target_blocks, g.tiles);
+  if (splits > g.nchunks / min_chunks) splits = g.nchunks / min_chunks;
   if (splits >= 8) splits = splits / 8 * 8;
   if (splits < 1) splits = 1;
-  a.chunks_per_split = cdiv(nchunks, splits);
-  splits = cdiv(nchunks, a.chunks_per_split);
+  a.chunks_per_split = cdiv(g.nchunks, splits);
+  splits = cdiv(g.nchunks, a.chunks_per_split);
   a.splits = splits;
-  dim3 grid(a.tilesCo * a.tilesCi * taps * splits), block(256);
-  {
-    const size_t esz = d->dtype == FRX_BF16 ? 2 : 4;
-    const size_t xb = (size_t)d->N * a.Hx * a.Wx * (d->stem ? 4 : d->Ci) * esz, yb = (size_t)a.M * d->Co * esz;
-    FRX_CHECK_ARG(xb < 0x80000000ull && yb < 0x80000000ull, "wgrad: tensors must stay below 2 GiB (32-bit buffer offsets)");
-    a.xbytes = (unsigned)xb; a.ybytes = (unsigned)yb;
+  return launch_wgrad((hipStream_t)stream, a, d->dtype, g.bt, g.wmode, in_scale != nullptr, pro_y != nullptr, g.tiles * splits);
+}
+
+// ---- grouped launch: table = [njobs] WgradArgs, then [nitems] WgradItem
+static inline size_t group_items_offset(int njobs) { return round_up((long)njobs * (long)sizeof(WgradArgs), 256); }
+static int group_chunks_per_item() { const char* e = getenv("FRX_WGRAD_GROUP_CHUNKS"); return e ? atoi(e) : 64; }
+
+static int group_build(const frx_wgrad_job* jobs, int njobs, std::vector<WgradArgs>* layers, std::vector<WgradItem>* items) {
+  FRX_CHECK_ARG(jobs && njobs > 0, "wgrad_group: no jobs");
+  const int target = group_chunks_per_item();
+  // (layer, split) groups stream the same pixel range: keep each on ONE XCD (block b runs on XCD b % 8, item p is
+  // taken by block p % grid), so its tiles share that L2.  Groups go round-robin to the least loaded XCD list.
+  std::vector<std::vector<WgradItem>> xl(8);
+  long load[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int li = 0; li < njobs; ++li) {
+    const frx_wgrad_job& j = jobs[li];
+    FRX_CHECK_ARG(j.d.dtype == jobs[0].d.dtype, "wgrad_group: all jobs must share a dtype");
+    WgradArgs a; WgradGeom g;
+    if (int rc = wgrad_args(&j.d, j.x, j.in_scale, j.in_shift, j.in_relu, j.dy, j.pro_y, j.pro_coef, j.dw, a, g)) return rc;
+    int splits = (g.nchunks + target / 2) / target;
+    if (splits < 1) splits = 1;
+    a.chunks_per_split = cdiv(g.nchunks, splits);
+    splits = cdiv(g.nchunks, a.chunks_per_split);
+    a.splits = splits;
+    if (layers) layers->push_back(a);
+    const long cost = (long)a.chunks_per_split * (g.bt == 128 ? 4 : 1);
+    for (int sp = 0; sp < splits; ++sp) {
+      int best = 0;
+      for (int x = 1; x < 8; ++x) if (load[x] < load[best]) best = x;
+      for (int tap = 0; tap < g.taps; ++tap)
+        for (int t = 0; t < a.tilesCo * a.tilesCi; ++t) xl[best].push_back(WgradItem{li, sp, t, tap});
+      load[best] += cost * g.tiles;
+    }
   }
-  const int wmode = d->stem ? WG_STEM : ((d->R == 1 && d->S == 1 && d->stride == 1) ? WG_POINTWISE : WG_GENERAL);
-  return launch_wgrad((hipStream_t)stream, a, d->dtype, bt, wmode, in_scale != nullptr, pro_y != nullptr, (int)grid.x);
+  size_t longest = 0;
+  for (auto& v : xl) longest = v.size() > longest ? v.size() : longest;
+  if (items) {
+    for (size_t k = 0; k < longest; ++k)
+      for (int x = 0; x < 8; ++x)
+        items->push_back(k < xl[x].size() ? xl[x][k] : WgradItem{-1, 0, 0, 0});     // -1: padding, skipped by the kernel
+  }
+  return (int)(longest * 8);
+}
+
+extern "C" int64_t frx_wgrad_group_bytes(const frx_wgrad_job* jobs, int njobs) {
+  const int n = group_build(jobs, njobs, nullptr, nullptr);
+  if (n < 0) return n;
+  return (int64_t)group_items_offset(njobs) + (int64_t)n * (int64_t)sizeof(WgradItem);
+}
+
+extern "C" int frx_wgrad_group_plan(int device, const frx_wgrad_job* jobs, int njobs, void* table_dev, int64_t table_bytes,
+                                    int* nitems) {
+  FRX_CHECK_ARG(table_dev && nitems, "wgrad_group_plan: NULL pointer");
+  std::vector<WgradArgs> layers; std::vector<WgradItem> items;
+  const int n = group_build(jobs, njobs, &layers, &items);
+  if (n < 0) return n;
+  const size_t off = group_items_offset(njobs), need = off + items.size() * sizeof(WgradItem);
+  FRX_CHECK_ARG((size_t)table_bytes >= need, "wgrad_group_plan: table needs %zu bytes, got %ld", need, (long)table_bytes);
+  FRX_ENTER(device);
+  FRX_HIP(hipMemcpy(table_dev, layers.data(), layers.size() * sizeof(WgradArgs), hipMemcpyHostToDevice));
+  FRX_HIP(hipMemcpy((char*)table_dev + off, items.data(), items.size() * sizeof(WgradItem), hipMemcpyHostToDevice));
+  *nitems = (int)items.size();
+  return FRX_OK;
+}
+
+extern "C" int frx_wgrad_group_run(int device, frx_stream_t stream, int dtype, const void* table_dev, int njobs, int nitems) {
+  FRX_CHECK_ARG(dtype == FRX_F32 || dtype == FRX_BF16, "wgrad_group_run: dtype");
+  FRX_CHECK_ARG(table_dev && njobs > 0 && nitems > 0, "wgrad_group_run: bad args");
+  FRX_ENTER(device);
+  return launch_wgrad_grouped((hipStream_t)stream, dtype, (const WgradArgs*)table_dev,
+                              (const WgradItem*)((const char*)table_dev + group_items_offset(njobs)), nitems);
 }
 
 extern "C" int frx_conv_wgrad(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x,

@@ -644,6 +644,7 @@ struct WgradArgs {
   int chunks_per_split;   // K-chunks (of KP pixels) per split
   int splits;
   unsigned xbytes, ybytes;  // sizes of X and dY (dY2) in bytes: buffer-load bounds
+  int variant;              // k_wgrad_grouped: WGV_* bits selecting the instantiation for this layer
 };
 
 // XOR swizzle of the 32-byte slot inside a pixel row so the 8 pixel rows a half-wave touches
@@ -658,9 +659,11 @@ enum { WG_POINTWISE = 0, WG_GENERAL = 1, WG_STEM = 2 };
 // WMODE: gather geometry of the X operand (compile-time: keeps the K loop straight-line so the
 // register ring gets counted vmcnt waits).  PRO: BN+ReLU prologue on X; a thread's channel group
 // is the same for every chunk, so its 8 scale / 8 shift values stay in registers.
+constexpr int WGRAD_SMEM = 2 * 2 * 32 * 256;       // bytes of LDS a 128 x 128 tile's two stages take (bf16 and fp32 alike)
+
+// One (co tile, ci tile, tap, pixel split) work item; all four indices block-uniform (SGPRs).
 template <typename T, int BT, int WMODE, bool PRO, bool YPRO>   // BT x BT output tile (co x ci)
-__global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
-  FRX_STAMP(0);
+__device__ __forceinline__ void wgrad_block(const WgradArgs& a, int split, int tile, int tap, char* smem) {
   constexpr int VEC = TT<T>::VEC;
   constexpr int KP = (sizeof(T) == 2) ? 32 : 16;   // pixels per K-chunk
   constexpr int RB = BT * sizeof(T);               // bytes per pixel row of a tile
@@ -669,16 +672,8 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
   constexpr int WT = BT / 2, F = WT / 16;          // 2x2 waves
   constexpr int PD = 3;                            // register ring depth (chunks in flight)
   static_assert(LD >= 1 && 256 % CPR == 0, "tile shape");
-  __shared__ __attribute__((aligned(16))) char smem[2 * 2 * KP * RB];
+  static_assert(2 * 2 * KP * RB <= WGRAD_SMEM, "LDS budget");
 
-  // 1-D grid, split index fastest: blocks that stream the SAME pixel range (same split, other
-  // tiles / taps) are `splits` apart in dispatch order, i.e. on one XCD when splits % 8 == 0.
-  // (integer division is expanded on the vector ALU: pin the block-uniform results back into SGPRs, or every
-  // buffer load that takes one of them as its scalar offset is wrapped in a waterfall loop)
-  const int split = __builtin_amdgcn_readfirstlane(blockIdx.x % a.splits);
-  const int rest = __builtin_amdgcn_readfirstlane(blockIdx.x / a.splits);
-  const int tile = __builtin_amdgcn_readfirstlane(rest % (a.tilesCo * a.tilesCi));
-  const int tap = __builtin_amdgcn_readfirstlane(rest / (a.tilesCo * a.tilesCi));
   const int cot = __builtin_amdgcn_readfirstlane(tile / a.tilesCi), cit = tile - cot * a.tilesCi;
   const int tr_ = __builtin_amdgcn_readfirstlane(tap / a.S), ts_ = tap - tr_ * a.S;
   const int co0 = cot * BT, ci0 = cit * BT;
@@ -952,10 +947,62 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
         }
       }
     }
+}
+
+template <typename T, int BT, int WMODE, bool PRO, bool YPRO>
+__global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
+  FRX_STAMP(0);
+  __shared__ __attribute__((aligned(16))) char smem[WGRAD_SMEM];
+  // 1-D grid, split index fastest: blocks that stream the SAME pixel range (same split, other
+  // tiles / taps) are `splits` apart in dispatch order, i.e. on one XCD when splits % 8 == 0.
+  // (integer division is expanded on the vector ALU: pin the block-uniform results back into SGPRs, or every
+  // buffer load that takes one of them as its scalar offset is wrapped in a waterfall loop)
+  const int split = __builtin_amdgcn_readfirstlane(blockIdx.x % a.splits);
+  const int rest = __builtin_amdgcn_readfirstlane(blockIdx.x / a.splits);
+  const int tile = __builtin_amdgcn_readfirstlane(rest % (a.tilesCo * a.tilesCi));
+  const int tap = __builtin_amdgcn_readfirstlane(rest / (a.tilesCo * a.tilesCi));
+  wgrad_block<T, BT, WMODE, PRO, YPRO>(a, split, tile, tap, smem);
 #ifdef FRX_DBG_TIMES
   __builtin_amdgcn_s_waitcnt(0);
   FRX_STAMP(3);
 #endif
+}
+
+// Every weight gradient of (a part of) the backward pass in ONE launch: persistent blocks walk a work list of
+// (layer, tile, tap, pixel split) items.  The items' fire-and-forget atomics drain while the block already
+// loads its next item, per-launch floors (53 of them) and the tails of 128-block launches disappear, and
+// one list balances layers of very different size across the whole GPU.
+struct WgradItem { int layer, split, tile, tap; };
+enum { WGV_BT128 = 1, WGV_GENERAL = 2, WGV_STEM = 4, WGV_PRO = 8, WGV_YPRO = 16 };   // WgradArgs::variant bits
+
+template <typename T>
+__global__ __launch_bounds__(256, 2) void k_wgrad_grouped(const WgradArgs* __restrict__ layers,
+                                                          const WgradItem* __restrict__ items, int nitems) {
+  __shared__ __attribute__((aligned(16))) char smem[WGRAD_SMEM];
+  for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
+    const WgradItem w = items[it];
+    const int li = __builtin_amdgcn_readfirstlane(w.layer);
+    if (li < 0) continue;                 // padding of the XCD-interleaved list
+    const WgradArgs a = layers[li];
+    const int split = __builtin_amdgcn_readfirstlane(w.split), tile = __builtin_amdgcn_readfirstlane(w.tile),
+              tap = __builtin_amdgcn_readfirstlane(w.tap);
+    const int v = __builtin_amdgcn_readfirstlane(a.variant);
+#define FRX_WGV(BT_, WM_, PRO_, YP_) wgrad_block<T, BT_, WM_, PRO_, YP_>(a, split, tile, tap, smem)
+    if (v & WGV_STEM) FRX_WGV(64, WG_STEM, false, false);
+    else if (v & WGV_BT128) {
+      if ((v & WGV_GENERAL) && (v & WGV_YPRO)) { if (v & WGV_PRO) FRX_WGV(128, WG_GENERAL, true, true); else FRX_WGV(128, WG_GENERAL, false, true); }
+      else if (v & WGV_GENERAL) { if (v & WGV_PRO) FRX_WGV(128, WG_GENERAL, true, false); else FRX_WGV(128, WG_GENERAL, false, false); }
+      else if (v & WGV_YPRO) { if (v & WGV_PRO) FRX_WGV(128, WG_POINTWISE, true, true); else FRX_WGV(128, WG_POINTWISE, false, true); }
+      else { if (v & WGV_PRO) FRX_WGV(128, WG_POINTWISE, true, false); else FRX_WGV(128, WG_POINTWISE, false, false); }
+    } else {
+      if ((v & WGV_GENERAL) && (v & WGV_YPRO)) { if (v & WGV_PRO) FRX_WGV(64, WG_GENERAL, true, true); else FRX_WGV(64, WG_GENERAL, false, true); }
+      else if (v & WGV_GENERAL) { if (v & WGV_PRO) FRX_WGV(64, WG_GENERAL, true, false); else FRX_WGV(64, WG_GENERAL, false, false); }
+      else if (v & WGV_YPRO) { if (v & WGV_PRO) FRX_WGV(64, WG_POINTWISE, true, true); else FRX_WGV(64, WG_POINTWISE, false, true); }
+      else { if (v & WGV_PRO) FRX_WGV(64, WG_POINTWISE, true, false); else FRX_WGV(64, WG_POINTWISE, false, false); }
+    }
+#undef FRX_WGV
+    __syncthreads();        // the next item re-uses the LDS stages
+  }
 }
 
 }  // namespace frx

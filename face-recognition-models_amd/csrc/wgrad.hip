@@ -1,5 +1,6 @@
 // k_wgrad instantiations.
 #include "conv_launch.h"
+#include <stdlib.h>
 namespace frx {
 #define FRX_WG(T_, BT_, WM_, PRO_, YP_) hipLaunchKernelGGL((k_wgrad<T_, BT_, WM_, PRO_, YP_>), dim3(grid), dim3(256), 0, st, a)
 #define FRX_WG_Y(T_, BT_, WM_, PRO_) do { if (ypro) FRX_WG(T_, BT_, WM_, PRO_, true); else FRX_WG(T_, BT_, WM_, PRO_, false); } while (0)
@@ -15,6 +16,18 @@ int launch_wgrad(hipStream_t st, const WgradArgs& a, int dtype, int bt, int wmod
   } else {
     if (bt == 64) FRX_WG_MODE(float, 64); else FRX_WG_MODE(float, 128);
   }
+  FRX_LAUNCH_CHECK();
+  return FRX_OK;
+}
+// persistent blocks: two per CU (the register budget of the widest variant), fewer when the list is short
+int launch_wgrad_grouped(hipStream_t st, int dtype, const WgradArgs* layers, const WgradItem* items, int nitems) {
+  const char* e = getenv("FRX_WGRAD_GROUP_BLOCKS");
+  int grid = e ? atoi(e) : 512;
+  if (grid > nitems) grid = nitems;
+  grid = grid / 8 * 8;
+  if (grid < 8) grid = 8;
+  if (dtype == FRX_BF16) hipLaunchKernelGGL(k_wgrad_grouped<bf16_t>, dim3(grid), dim3(256), 0, st, layers, items, nitems);
+  else hipLaunchKernelGGL(k_wgrad_grouped<float>, dim3(grid), dim3(256), 0, st, layers, items, nitems);
   FRX_LAUNCH_CHECK();
   return FRX_OK;
 }

@@ -30,6 +30,13 @@ class DgradFuse(C.Structure):
                 + [("addend_stride", C.c_int32), ("pro_dy_out", C.c_void_p)])
 
 
+class WgradJob(C.Structure):
+    """frx_wgrad_job (include/frx.h)"""
+    _fields_ = [("d", ConvDesc), ("x", C.c_void_p), ("in_scale", C.c_void_p), ("in_shift", C.c_void_p),
+                ("in_relu", C.c_int32), ("dy", C.c_void_p), ("pro_y", C.c_void_p), ("pro_coef", C.c_void_p),
+                ("dw", C.c_void_p)]
+
+
 def library_path() -> str:
     return _LIB_PATH
 
@@ -53,6 +60,9 @@ _SIGS = {
     "frx_conv_dgrad": (C.c_int, [C.c_int, _P, C.POINTER(ConvDesc), _P, _P, _P, _P]),
     "frx_conv_wgrad": (C.c_int, [C.c_int, _P, C.POINTER(ConvDesc), _P, _P, _P, C.c_int, _P, _P]),
     "frx_conv_dgrad_stat_rows": (C.c_int, [C.POINTER(ConvDesc)]),
+    "frx_wgrad_group_bytes": (C.c_int64, [C.POINTER(WgradJob), C.c_int]),
+    "frx_wgrad_group_plan": (C.c_int, [C.c_int, C.POINTER(WgradJob), C.c_int, _P, C.c_int64, C.POINTER(C.c_int)]),
+    "frx_wgrad_group_run": (C.c_int, [C.c_int, _P, C.c_int, _P, C.c_int, C.c_int]),
     "frx_conv_dgrad_bn": (C.c_int, [C.c_int, _P, C.POINTER(ConvDesc), _P, _P, _P, _P, C.POINTER(DgradFuse)]),
     "frx_conv_wgrad_bn": (C.c_int, [C.c_int, _P, C.POINTER(ConvDesc), _P, _P, _P, C.c_int, _P, _P, _P, _P]),
     "frx_bn_finalize": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int64, _P, _P, C.c_float, C.c_float,

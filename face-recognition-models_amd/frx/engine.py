@@ -15,6 +15,7 @@ from __future__ import annotations
 import math
 from dataclasses import dataclass, field
 
+import os
 import torch
 
 from . import ops
@@ -60,6 +61,11 @@ class BlockSpec:
     conv3: ConvSpec
     down: ConvSpec | None
     out: torch.Tensor = None
+    # backward buffers that live until the optimiser step (the grouped weight-gradient launch reads them late)
+    dz3: torch.Tensor = None     # masked gradient of the block output (feeds bn3, the identity and the projection)
+    dy2: torch.Tensor = None     # gradient of conv2's raw output
+    dyc: dict = None             # conv name -> copy of dy kept by its dgrad (where _keeps_dy says so)
+    coefs: list = None           # BN-backward coefficients of bn3 / bn2 / bn1 / downsample
 
 
 def resnet50_specs(H=112):
@@ -159,6 +165,10 @@ class ResNet50Engine:
         self.pool_arg = torch.empty(N, self.hpool, self.hpool, 64, dtype=torch.uint8, device=dev)
         for b in self.blocks:
             b.out = torch.empty_like(b.conv3.y)
+            b.dz3 = torch.empty_like(b.conv3.y)
+            b.dy2 = torch.empty_like(b.conv2.y)
+            b.dyc = {c.name: torch.empty_like(c.y) for c in (b.conv1, b.conv3, b.down) if c is not None and self._keeps_dy(c)}
+            b.coefs = [torch.empty(3 * c.Co, device=dev) if c is not None else None for c in (b.conv3, b.conv2, b.conv1, b.down)]
         self.pooled = torch.empty(N, 2048, dtype=self.tdt, device=dev)
         self.feats = torch.empty(N, FEATURE_DIM, device=dev)
         self.fc_desc = ops.conv_desc(dtype, N, 1, 1, 2048, FEATURE_DIM, 1, 1, 1, 0)
@@ -176,7 +186,10 @@ class ResNet50Engine:
         max_bp = max([max_bp] + [ops.conv_dgrad_stat_rows(c.desc) * c.Ci for c in self.convs if not c.stem])
         self.bwd_partial = torch.empty(2 * max_bp, device=dev)
         self.coef = torch.empty(3 * 2048, device=dev)
-        self.coefs = [torch.empty(3 * 2048, device=dev) for _ in range(4)]     # bn3 / bn2 / bn1 / downsample in flight
+        self.g_pool = torch.empty_like(self.pool_out)        # gradient w.r.t. the max-pool output
+        self.dy_stem = torch.empty_like(self.stem.y)
+        self.grouped_wgrad = os.environ.get("FRX_WGRAD_GROUPED", "1") != "0"
+        self._wg_groups = None                               # planned lazily (needs every buffer above)
         self.dfeat_t = torch.empty(N, FEATURE_DIM, dtype=self.tdt, device=dev)
         self.lr_dev = torch.zeros(1, device=dev)
         self.training = True
@@ -389,7 +402,6 @@ class ResNet50Engine:
         reduce / apply kernels."""
         N, dt = self.N, self.dtype
         S = self.scratch
-        C3, C2, C1, CD = self.coefs
         # fc
         ops.cast(dt, dfeat, self.dfeat_t, to_f32=False)
         ops.conv_wgrad(self.fc_desc, self.pooled, self.dfeat_t, self.fc_w(self.grads))
@@ -400,43 +412,41 @@ class ResNet50Engine:
         g = self._like(S[3], last.out)
         ops.avgpool_bwd(dt, N, self.h_final * self.h_final, 2048, dpool, g)
         # last block: its output gradient comes from the pool, so mask + reduce run stand-alone
-        gi = 0
         c3 = last.conv3
         rows3 = c3.y.numel() // c3.Co
-        dz3 = self._like(S[gi], c3.y)
         ops.bn_bwd_reduce(dt, rows3, c3.Co, g, c3.y, self._bn(self.bn_mean, c3), self._bn(self.bn_invstd, c3),
-                          self.bwd_partial, out=last.out, dz_out=dz3)
-        self._bw_state = (gi, ops.bn_bwd_partial_rows(rows3, c3.Co))
+                          self.bwd_partial, out=last.out, dz_out=last.dz3)
+        self._bw_npart = ops.bn_bwd_partial_rows(rows3, c3.Co)
         self._backward_blocks(len(self.blocks) - 1, self.SPLIT_BLOCK)
+        self._run_wgrad_group(0)
 
     def backward_lower(self):
         self._backward_blocks(self.SPLIT_BLOCK - 1, 0)
         self._backward_stem()
+        self._run_wgrad_group(1)
 
     def _backward_blocks(self, hi, lo):
         N, dt = self.N, self.dtype
         S = self.scratch
-        C3, C2, C1, CD = self.coefs
-        gi, npart = self._bw_state
+        npart = self._bw_npart
         for bi in range(hi, lo - 1, -1):
             b = self.blocks[bi]
             prev = self.blocks[bi - 1] if bi > 0 else None
             x_in = prev.out if prev is not None else self.pool_out
             c1, c2, c3, ds = b.conv1, b.conv2, b.conv3, b.down
-            dz3 = self._like(S[gi], c3.y)                         # masked block-output gradient (feeds bn3 AND the identity)
+            C3, C2, C1, CD = b.coefs
+            dz3 = b.dz3
             self._finalize_bwd(c3, npart, C3)
             # conv3 (1x1): the dgrad evaluates dy3 = affine(dz3, y3) while staging its tiles and handles bn2 in its epilogue
             dz2 = self._like(S[4], c2.y)
-            self._bwd_1x1(c3, dz3, C3, c2.y, dz2, S[5], x_bn=c2, **self._epi(c2))
+            self._bwd_1x1(b, c3, dz3, C3, c2.y, dz2, x_bn=c2, **self._epi(c2))
             self._finalize_bwd(c2, ops.conv_dgrad_stat_rows(c3.desc), C2)
             # conv2 (3x3): materialise dy2 once (9 taps would re-evaluate a prologue 9 times)
-            dy2 = self._like(S[3], c2.y)
             rows2 = c2.y.numel() // c2.Co
-            ops.bn_bwd_apply(dt, rows2, c2.Co, dz2, c2.y, self._bn(self.bn_mean, c2), self._bn(self.bn_invstd, c2), C2, dy2)
-            ops.conv_wgrad(c2.desc, c1.y, dy2, self.w_grad(c2), in_scale=self._bn(self.bn_scale, c1),
-                           in_shift=self._bn(self.bn_shift, c1), in_relu=True)
+            ops.bn_bwd_apply(dt, rows2, c2.Co, dz2, c2.y, self._bn(self.bn_mean, c2), self._bn(self.bn_invstd, c2), C2, b.dy2)
+            self._wgrad(c2, c1.y, b.dy2, x_bn=c1)
             dz1 = self._like(S[4], c1.y)
-            ops.conv_dgrad_bn(c2.desc, dy2, c2.wt, dz1, **self._epi(c1))
+            ops.conv_dgrad_bn(c2.desc, b.dy2, c2.wt, dz1, **self._epi(c1))
             self._finalize_bwd(c1, ops.conv_dgrad_stat_rows(c2.desc), C1)
             addend, add_stride = dz3, 0
             if ds is not None:
@@ -452,46 +462,87 @@ class ResNet50Engine:
                     add_stride = 2
                 else:
                     addend = self._like(S[2], x_in)
-                self._bwd_1x1(ds, dz3, CD, x_in, addend, S[5])
-            # conv1 (1x1)
-            gnext = self._like(S[1 - gi], x_in)
+                self._bwd_1x1(b, ds, dz3, CD, x_in, addend)
+            # conv1 (1x1): its dgrad writes the masked output gradient of the block below (or the pool's)
             if prev is not None:      # epilogue: merge-ReLU mask of the block below + its bn3 reduce
-                self._bwd_1x1(c1, dz1, C1, x_in, gnext, S[5], addend=addend, addend_stride=add_stride,
+                self._bwd_1x1(b, c1, dz1, C1, x_in, prev.dz3, addend=addend, addend_stride=add_stride,
                               **self._epi(prev.conv3, out=prev.out))
                 npart = ops.conv_dgrad_stat_rows(c1.desc)
             else:
-                self._bwd_1x1(c1, dz1, C1, x_in, gnext, S[5], addend=addend, addend_stride=add_stride)
-            gi = 1 - gi
-        self._bw_state = (gi, npart)
+                self._bwd_1x1(b, c1, dz1, C1, x_in, self.g_pool, addend=addend, addend_stride=add_stride)
+        self._bw_npart = npart
 
-    def _bwd_1x1(self, c, dz, coef, x, dx, dy_buf, x_bn=None, addend=None, **epi):
-        """Input and weight gradient of a 1x1 conv whose BN backward is fused (dy = alpha*dz + beta*y + gam).
-        Where writing dy once is cheaper than evaluating it twice -- narrow dy, or deep layers whose wgrad is
-        ALU-bound -- the dgrad keeps a copy for the wgrad (measured per layer type, scripts/layer_times.py);
-        otherwise both kernels evaluate it on the fly (layer1/2 conv3 and the stride-2 projections are HBM-bound)."""
-        pro = {} if x_bn is None else dict(in_scale=self._bn(self.bn_scale, x_bn), in_shift=self._bn(self.bn_shift, x_bn),
-                                           in_relu=True)
+    @staticmethod
+    def _keeps_dy(c):
+        """1x1 convs whose dgrad keeps a copy of dy = alpha*dz + beta*y + gam for the weight gradient: where writing dy
+        once is cheaper than evaluating it twice -- narrow dy, or deep layers whose wgrad is ALU-bound (measured per
+        layer type, scripts/layer_times.py).  Elsewhere (layer1/2 conv3, the projections: HBM-bound) both evaluate it."""
+        return c.k == 1 and (c.Co <= c.Ci or (c.Co >= 1024 and c.stride == 1))
+
+    def _bwd_1x1(self, b, c, dz, coef, x, dx, x_bn=None, addend=None, **epi):
+        """input and weight gradient of a 1x1 conv whose BN backward is fused (dy = alpha*dz + beta*y + gam)"""
         dd = c.desc_c if c.desc_c is not None else c.desc      # dgrad geometry (compact for stride-2 projections)
-        if c.Co <= c.Ci or (c.Co >= 1024 and c.desc.stride == 1):
-            dy = self._like(dy_buf, c.y)
+        if self._keeps_dy(c):
+            dy = b.dyc[c.name]
             ops.conv_dgrad_bn(dd, dz, c.wt, dx, addend=addend, pro_y=c.y, pro_coef=coef, pro_dy_out=dy, **epi)
-            ops.conv_wgrad(c.desc, x, dy, self.w_grad(c), **pro)
+            self._wgrad(c, x, dy, x_bn=x_bn)
         else:
-            ops.conv_wgrad_bn(c.desc, x, dz, c.y, coef, self.w_grad(c), **pro)
+            self._wgrad(c, x, dz, x_bn=x_bn, pro_y=c.y, pro_coef=coef)
             ops.conv_dgrad_bn(dd, dz, c.wt, dx, addend=addend, pro_y=c.y, pro_coef=coef, **epi)
 
     def _backward_stem(self):
         # stem: max-pool -> ReLU/BN -> conv weight gradient (no image gradient)
         N, dt = self.N, self.dtype
         S = self.scratch
-        gi, _ = self._bw_state
-        g = self._like(S[gi], self.pool_out)
         s = self.stem
         dpost = self._like(S[2], s.y)
-        ops.stem_pool_bwd(dt, N, s.Ho, s.Ho, 64, g, self.pool_arg, dpost)
-        dy0 = self._like(S[3], s.y)
-        self._bn_backward(s, dpost, dy0, relu=True)
-        ops.conv_wgrad(s.desc, self.xin, dy0, self.w_grad(s))     # (padding tap / channel slots are not written)
+        ops.stem_pool_bwd(dt, N, s.Ho, s.Ho, 64, self.g_pool, self.pool_arg, dpost)
+        self._bn_backward(s, dpost, self.dy_stem, relu=True)
+        self._wgrad(s, self.xin, self.dy_stem)     # (padding tap / channel slots are not written)
+
+    # ------------------------------------------------------------------ weight gradients
+    def _wgrad_job(self, c, x, dy, x_bn=None, pro_y=None, pro_coef=None):
+        pro = {} if x_bn is None else dict(in_scale=self._bn(self.bn_scale, x_bn), in_shift=self._bn(self.bn_shift, x_bn),
+                                           in_relu=True)
+        return dict(d=c.desc, x=x, dy=dy, dw=self.w_grad(c), pro_y=pro_y, pro_coef=pro_coef, **pro)
+
+    def _wgrad(self, c, x, dy, x_bn=None, pro_y=None, pro_coef=None):
+        """per-layer launch -- or nothing when the grouped launch covers this layer (same operands, planned once)"""
+        if self.grouped_wgrad:
+            return
+        j = self._wgrad_job(c, x, dy, x_bn, pro_y, pro_coef)
+        kw = {k: j[k] for k in ("in_scale", "in_shift", "in_relu") if k in j}
+        if pro_y is not None:
+            ops.conv_wgrad_bn(c.desc, x, dy, pro_y, pro_coef, j["dw"], **kw)
+        else:
+            ops.conv_wgrad(c.desc, x, dy, j["dw"], **kw)
+
+    def _plan_wgrad_groups(self):
+        """Two work lists of persistent-block weight-gradient items: [upper blocks] and [lower blocks + stem]
+        (data-parallel training all-reduces the upper gradients while the lower backward still runs)."""
+        groups = [[], []]
+        for bi, b in enumerate(self.blocks):
+            jobs = groups[0] if bi >= self.SPLIT_BLOCK else groups[1]
+            x_in = self.blocks[bi - 1].out if bi > 0 else self.pool_out
+            C3, C2, C1, CD = b.coefs
+            for c, x, xb, dz, coef in ((b.conv3, b.conv2.y, b.conv2, b.dz3, C3), (b.down, x_in, None, b.dz3, CD),
+                                       (b.conv1, x_in, None, None, C1)):
+                if c is None:
+                    continue
+                if self._keeps_dy(c):
+                    jobs.append(self._wgrad_job(c, x, b.dyc[c.name], x_bn=xb))
+                else:
+                    jobs.append(self._wgrad_job(c, x, dz, x_bn=xb, pro_y=c.y, pro_coef=coef))
+            jobs.append(self._wgrad_job(b.conv2, b.conv1.y, b.dy2, x_bn=b.conv1))
+        groups[1].append(self._wgrad_job(self.stem, self.xin, self.dy_stem))
+        self._wg_groups = [ops.wgrad_group_plan(self.dtype, jobs) for jobs in groups]
+
+    def _run_wgrad_group(self, which):
+        if not self.grouped_wgrad:
+            return
+        if self._wg_groups is None:
+            self._plan_wgrad_groups()
+        ops.wgrad_group_run(self._wg_groups[which])
 
     # ------------------------------------------------------------------ optimiser
     def zero_grad(self):

@@ -58,6 +58,11 @@ def _p(t):
     return C.c_void_p(0 if t is None else t.data_ptr())
 
 
+def _pv(t):
+    """device address for a ctypes struct field (None -> NULL)"""
+    return None if t is None else t.data_ptr()
+
+
 def _chk(t, dtype, name):
     if t.dtype != dtype or not t.is_contiguous():
         raise FrxError(f"{name}: expected contiguous {dtype}, got {t.dtype} contiguous={t.is_contiguous()}")
@@ -226,6 +231,40 @@ def conv_wgrad(d, x, dy, dw, in_scale=None, in_shift=None, in_relu=False):
                                   int(in_relu), _p(dy), _p(dw)), "frx_conv_wgrad"),
         nbytes=conv_bytes(d, wbytes=dw.numel() * 4))
     return dw
+
+
+class WgradGroup:
+    """a planned frx_wgrad_group table (device) plus everything that must outlive it"""
+    __slots__ = ("table", "njobs", "nitems", "dtype", "flops", "keep")
+
+
+def wgrad_group_plan(dtype, jobs):
+    """jobs: dicts with d (ConvDesc), x, dy, dw and optionally in_scale / in_shift / in_relu / pro_y / pro_coef.
+    The tensors' addresses are captured: they must stay allocated (and in place) while the group is used."""
+    arr = (_lib.WgradJob * len(jobs))()
+    for i, j in enumerate(jobs):
+        arr[i] = _lib.WgradJob(j["d"], _pv(j["x"]), _pv(j.get("in_scale")), _pv(j.get("in_shift")),
+                               int(bool(j.get("in_relu", False))), _pv(j["dy"]), _pv(j.get("pro_y")),
+                               _pv(j.get("pro_coef")), _pv(j["dw"]))
+    nbytes = _lib.lib().frx_wgrad_group_bytes(arr, len(jobs))
+    if nbytes < 0:
+        raise FrxError("frx_wgrad_group_bytes: " + _lib.lib().frx_last_error().decode())
+    dev = jobs[0]["x"].device
+    g = WgradGroup()
+    g.table = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    n = C.c_int(0)
+    check(_lib.lib().frx_wgrad_group_plan(dev.index or 0, arr, len(jobs), _p(g.table), nbytes, C.byref(n)),
+          "frx_wgrad_group_plan")
+    g.njobs, g.nitems, g.dtype = len(jobs), n.value, dtype
+    g.flops = sum(conv_flops(j["d"]) for j in jobs)
+    g.keep = [t for j in jobs for t in j.values() if isinstance(t, torch.Tensor)]
+    return g
+
+
+def wgrad_group_run(g):
+    _timed(f"k_wgrad_grouped<{_dt_name(g.dtype)}>", g.flops, g.table, lambda: check(
+        _lib.lib().frx_wgrad_group_run(_dev(g.table), _stream(g.table), g.dtype, _p(g.table), g.njobs, g.nitems),
+        "frx_wgrad_group_run"))
 
 
 def conv_dgrad_stat_rows(d):

@@ -169,6 +169,25 @@ int frx_conv_wgrad_bn(int device, frx_stream_t stream, const frx_conv_desc* d, c
 int frx_conv_wgrad(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x, const float* in_scale,
                    const float* in_shift, int in_relu, const void* dy, float* dw);
 
+/* All weight gradients of (a part of) the backward pass in ONE launch of persistent blocks (the per-layer calls
+ * above each pay a launch floor, a ring fill and an atomics tail, and half of them cannot fill the GPU).
+ * Pointers are captured when the table is planned: plan once, run every step.  dw is accumulated like frx_conv_wgrad. */
+typedef struct frx_wgrad_job {
+  frx_conv_desc d;
+  const void* x;             /* conv input activation (raw when in_scale is given) */
+  const float* in_scale;     /* optional BN+ReLU prologue on x, as in frx_conv_wgrad */
+  const float* in_shift;
+  int32_t in_relu;
+  const void* dy;            /* dy -- or dz when pro_y / pro_coef are given (frx_conv_wgrad_bn) */
+  const void* pro_y;
+  const float* pro_coef;
+  float* dw;
+} frx_wgrad_job;
+int64_t frx_wgrad_group_bytes(const frx_wgrad_job* jobs, int njobs);          /* size of the device table; < 0: error */
+int frx_wgrad_group_plan(int device, const frx_wgrad_job* jobs, int njobs, void* table_dev, int64_t table_bytes,
+                         int* nitems);                                        /* synchronous (host -> device copy) */
+int frx_wgrad_group_run(int device, frx_stream_t stream, int dtype, const void* table_dev, int njobs, int nitems);
+
 /* ---------------------------------------------------------------- backbone: BatchNorm / ReLU / residual / pools
  * Replace nn.BatchNorm2d x53 (train: batch statistics + running-stat update, momentum 0.1, eps 1e-5;
  * eval: running statistics), nn.ReLU, the residual add, MaxPool2d(3,2,1), AdaptiveAvgPool2d(1). */

@@ -261,3 +261,48 @@ def test_dgrad_compact_stride2_addend(dtype, shape):
     out = torch.empty_like(ref)
     ops.conv_dgrad_bn(d, dz, wt, out, addend=compact, pro_y=y, pro_coef=coef, addend_stride=2)
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("dtype", [0, 1], ids=["f32", "bf16"])
+def test_grouped_wgrad_matches_per_layer(dtype):
+    """frx_wgrad_group_*: one persistent launch over a work list == the per-layer frx_conv_wgrad / frx_conv_wgrad_bn
+    calls (every kernel variant: 1x1 / 3x3 / stride 2 / stem, with and without the two prologues, both tile sizes)."""
+    from frx import ops
+    N = 5
+    T = ops.TORCH_DT[dtype]
+    g = torch.Generator().manual_seed(11)
+    shapes = [(64, 256, 1, 1, 14, True, True), (256, 64, 1, 1, 14, False, False), (128, 128, 3, 1, 14, True, False),
+              (128, 128, 3, 2, 14, True, False), (256, 512, 1, 2, 14, False, True), (64, 64, 3, 1, 28, False, False),
+              (512, 128, 1, 1, 7, True, False), (64, 64, 1, 1, 28, True, True)]
+    jobs, refs = [], []
+    for (Ci, Co, k, st, Hi, pro, ypro) in shapes:
+        d = ops.conv_desc(dtype, N, Hi, Hi, Ci, Co, k, k, st, k // 2)
+        x = _mk(dtype, N, Hi, Hi, Ci, seed=Ci + Co).to(DEV)
+        dy = _mk(dtype, N, d.Ho, d.Wo, Co, seed=Ci + 1).to(DEV)
+        y = _mk(dtype, N, d.Ho, d.Wo, Co, seed=Ci + 2).to(DEV)
+        sc, sh = (torch.rand(Ci, generator=g) + 0.5).to(DEV), (torch.randn(Ci, generator=g) * 0.3).to(DEV)
+        coef = torch.cat([torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g) * 0.2, torch.randn(Co, generator=g) * 0.1]).to(DEV)
+        kw = dict(in_scale=sc, in_shift=sh, in_relu=True) if pro else {}
+        ref = torch.zeros(Co, k, k, Ci, device=DEV)
+        if ypro and k == 1:
+            ops.conv_wgrad_bn(d, x, dy, y, coef, ref, **kw)
+            jobs.append(dict(d=d, x=x, dy=dy, pro_y=y, pro_coef=coef, dw=torch.zeros_like(ref), **kw))
+        else:
+            ops.conv_wgrad(d, x, dy, ref, **kw)
+            jobs.append(dict(d=d, x=x, dy=dy, dw=torch.zeros_like(ref), **kw))
+        refs.append(ref)
+    H = 16
+    hp, wp = ops.stem_padded_dims(H, H)
+    ds = ops.conv_desc(dtype, N, H, H, 3, 64, 7, 7, 2, 3, stem=True)
+    xin = torch.zeros(N, hp, wp, 4, dtype=T, device=DEV)
+    xin[:, 3:3 + H, 3:3 + H, :3] = _mk(dtype, N, H, H, 3, seed=77).to(DEV)
+    dys = _mk(dtype, N, ds.Ho, ds.Wo, 64, seed=78).to(DEV)
+    ref = torch.zeros(64, 7, 8, 4, device=DEV)
+    ops.conv_wgrad(ds, xin, dys, ref)
+    jobs.append(dict(d=ds, x=xin, dy=dys, dw=torch.zeros_like(ref)))
+    refs.append(ref)
+    grp = ops.wgrad_group_plan(dtype, jobs)
+    ops.wgrad_group_run(grp)
+    ops.wgrad_group_run(grp)            # accumulates like the per-layer calls
+    for j, r in zip(jobs, refs):
+        _close(j["dw"] * 0.5, r.cpu(), dtype, "grouped wgrad %s" % (tuple(r.shape),))
