@@ -181,7 +181,7 @@ class ResNet50Engine:
         max_rows = max(c.stat_rows * c.Co for c in self.convs)
         self.stat_partial = torch.empty(2 * max_rows, device=dev)
         max_act = max(c.y.numel() for c in self.convs)
-        self.scratch = [torch.empty(max_act, dtype=self.tdt, device=dev) for _ in range(6)]
+        self.scratch = [torch.empty(max_act, dtype=self.tdt, device=dev) for _ in range(5)]
         max_bp = max(ops.bn_bwd_partial_rows(c.y.numel() // c.Co, c.Co) * c.Co for c in self.convs)
         max_bp = max([max_bp] + [ops.conv_dgrad_stat_rows(c.desc) * c.Ci for c in self.convs if not c.stem])
         self.bwd_partial = torch.empty(2 * max_bp, device=dev)

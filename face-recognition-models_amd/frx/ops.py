@@ -235,7 +235,7 @@ def conv_wgrad(d, x, dy, dw, in_scale=None, in_shift=None, in_relu=False):
 
 class WgradGroup:
     """a planned frx_wgrad_group table (device) plus everything that must outlive it"""
-    __slots__ = ("table", "njobs", "nitems", "dtype", "flops", "keep")
+    __slots__ = ("table", "njobs", "nitems", "dtype", "flops", "nbytes", "keep")
 
 
 def wgrad_group_plan(dtype, jobs):
@@ -257,6 +257,7 @@ def wgrad_group_plan(dtype, jobs):
           "frx_wgrad_group_plan")
     g.njobs, g.nitems, g.dtype = len(jobs), n.value, dtype
     g.flops = sum(conv_flops(j["d"]) for j in jobs)
+    g.nbytes = sum(conv_bytes(j["d"], n_out=2 if j.get("pro_y") is not None else 1, wbytes=j["dw"].numel() * 4) for j in jobs)
     g.keep = [t for j in jobs for t in j.values() if isinstance(t, torch.Tensor)]
     return g
 
@@ -264,7 +265,7 @@ def wgrad_group_plan(dtype, jobs):
 def wgrad_group_run(g):
     _timed(f"k_wgrad_grouped<{_dt_name(g.dtype)}>", g.flops, g.table, lambda: check(
         _lib.lib().frx_wgrad_group_run(_dev(g.table), _stream(g.table), g.dtype, _p(g.table), g.njobs, g.nitems),
-        "frx_wgrad_group_run"))
+        "frx_wgrad_group_run"), nbytes=g.nbytes)
 
 
 def conv_dgrad_stat_rows(d):
