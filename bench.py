@@ -225,14 +225,17 @@ def run():
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    loss_trace = torch.zeros(args.steps, device=dev)      # one 4-byte device copy per step, read after the timed region
     t0 = time.perf_counter()
     for i in range(args.steps):
         o = step(i)
+        loss_trace[i].copy_(o["loss"].reshape(()))
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     dt_s = time.perf_counter() - t0
     loss = float(o["loss"].item())
+    log("loss per step: " + " ".join(f"{v:.1f}" for v in loss_trace.tolist()))
     log(f"timed region done: {dt_s / args.steps * 1e3:.3f} ms/step")
     tmax = torch.tensor([dt_s], device=dev, dtype=torch.float64)
     if world > 1:

@@ -157,20 +157,20 @@ class ResNet50Engine:
                 c.wk = torch.zeros(c.Co, c.k, c.k, c.Ci, dtype=self.tdt, device=dev)
                 c.wt = torch.zeros(c.Ci, c.k, c.k, c.Co, dtype=self.tdt, device=dev)
             c.stat_rows = ops.conv_stat_rows(c.desc)
-            c.y = torch.empty(N, c.Ho, c.Ho, c.Co, dtype=self.tdt, device=dev)
+            c.y = torch.zeros(N, c.Ho, c.Ho, c.Co, dtype=self.tdt, device=dev)
         hp, wp = ops.stem_padded_dims(H, H)
         self.xin = torch.zeros(N, hp, wp, 4, dtype=self.tdt, device=dev)
         self.hpool = (self.stem.Ho + 2 - 3) // 2 + 1
-        self.pool_out = torch.empty(N, self.hpool, self.hpool, 64, dtype=self.tdt, device=dev)
-        self.pool_arg = torch.empty(N, self.hpool, self.hpool, 64, dtype=torch.uint8, device=dev)
+        self.pool_out = torch.zeros(N, self.hpool, self.hpool, 64, dtype=self.tdt, device=dev)
+        self.pool_arg = torch.zeros(N, self.hpool, self.hpool, 64, dtype=torch.uint8, device=dev)
         for b in self.blocks:
-            b.out = torch.empty_like(b.conv3.y)
-            b.dz3 = torch.empty_like(b.conv3.y)
-            b.dy2 = torch.empty_like(b.conv2.y)
-            b.dyc = {c.name: torch.empty_like(c.y) for c in (b.conv1, b.conv3, b.down) if c is not None and self._keeps_dy(c)}
-            b.coefs = [torch.empty(3 * c.Co, device=dev) if c is not None else None for c in (b.conv3, b.conv2, b.conv1, b.down)]
-        self.pooled = torch.empty(N, 2048, dtype=self.tdt, device=dev)
-        self.feats = torch.empty(N, FEATURE_DIM, device=dev)
+            b.out = torch.zeros_like(b.conv3.y)
+            b.dz3 = torch.zeros_like(b.conv3.y)
+            b.dy2 = torch.zeros_like(b.conv2.y)
+            b.dyc = {c.name: torch.zeros_like(c.y) for c in (b.conv1, b.conv3, b.down) if c is not None and self._keeps_dy(c)}
+            b.coefs = [torch.zeros(3 * c.Co, device=dev) if c is not None else None for c in (b.conv3, b.conv2, b.conv1, b.down)]
+        self.pooled = torch.zeros(N, 2048, dtype=self.tdt, device=dev)
+        self.feats = torch.zeros(N, FEATURE_DIM, device=dev)
         self.fc_desc = ops.conv_desc(dtype, N, 1, 1, 2048, FEATURE_DIM, 1, 1, 1, 0)
         if share is not None:
             self.fc_wk, self.fc_wt = share.fc_wk, share.fc_wt
@@ -179,18 +179,18 @@ class ResNet50Engine:
             self.fc_wt = torch.zeros(2048, FEATURE_DIM, dtype=self.tdt, device=dev)
         # ---- scratch
         max_rows = max(c.stat_rows * c.Co for c in self.convs)
-        self.stat_partial = torch.empty(2 * max_rows, device=dev)
+        self.stat_partial = torch.zeros(2 * max_rows, device=dev)
         max_act = max(c.y.numel() for c in self.convs)
-        self.scratch = [torch.empty(max_act, dtype=self.tdt, device=dev) for _ in range(5)]
+        self.scratch = [torch.zeros(max_act, dtype=self.tdt, device=dev) for _ in range(5)]
         max_bp = max(ops.bn_bwd_partial_rows(c.y.numel() // c.Co, c.Co) * c.Co for c in self.convs)
         max_bp = max([max_bp] + [ops.conv_dgrad_stat_rows(c.desc) * c.Ci for c in self.convs if not c.stem])
-        self.bwd_partial = torch.empty(2 * max_bp, device=dev)
-        self.coef = torch.empty(3 * 2048, device=dev)
-        self.g_pool = torch.empty_like(self.pool_out)        # gradient w.r.t. the max-pool output
-        self.dy_stem = torch.empty_like(self.stem.y)
+        self.bwd_partial = torch.zeros(2 * max_bp, device=dev)
+        self.coef = torch.zeros(3 * 2048, device=dev)
+        self.g_pool = torch.zeros_like(self.pool_out)        # gradient w.r.t. the max-pool output
+        self.dy_stem = torch.zeros_like(self.stem.y)
         self.grouped_wgrad = os.environ.get("FRX_WGRAD_GROUPED", "1") != "0"
         self._wg_groups = None                               # planned lazily (needs every buffer above)
-        self.dfeat_t = torch.empty(N, FEATURE_DIM, dtype=self.tdt, device=dev)
+        self.dfeat_t = torch.zeros(N, FEATURE_DIM, dtype=self.tdt, device=dev)
         self.lr_dev = torch.zeros(1, device=dev)
         self.training = True
         self._eval_affine_ready = False
@@ -629,7 +629,7 @@ class FaceEngine:
         # CurricularFace buffer `t` (criterion.py:517)
         self.t = torch.zeros(1, device=self.device) if share is None else share.t
         self.sphere_iter = 0                                 # SphereFace.iter (criterion.py:33): python int
-        self.dfeat = torch.empty(batch, FEATURE_DIM, device=self.device)
+        self.dfeat = torch.zeros(batch, FEATURE_DIM, device=self.device)
         self.last = None
         self.world = 1
         self.allreduce = None                                # callable(flat fp32 grads) for data parallel

@@ -76,7 +76,7 @@ class HeadContext:
         nbytes = _lib.lib().frx_head_workspace_bytes(C.byref(self.desc))
         if nbytes == 0:
             raise FrxError("head descriptor rejected: " + _lib.lib().frx_last_error().decode())
-        self.ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        self.ws = torch.zeros(nbytes, dtype=torch.uint8, device=device)
         self.nbytes = nbytes
 
     @property
@@ -251,7 +251,7 @@ def wgrad_group_plan(dtype, jobs):
         raise FrxError("frx_wgrad_group_bytes: " + _lib.lib().frx_last_error().decode())
     dev = jobs[0]["x"].device
     g = WgradGroup()
-    g.table = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    g.table = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
     n = C.c_int(0)
     check(_lib.lib().frx_wgrad_group_plan(dev.index or 0, arr, len(jobs), _p(g.table), nbytes, C.byref(n)),
           "frx_wgrad_group_plan")
