@@ -165,6 +165,7 @@ def run():
 
     def capture(fn):
         """warm up on a side stream, then capture fn into a hipGraph"""
+        side.wait_stream(torch.cuda.current_stream())      # the warm-up must see the initialisation / feed() queued so far
         with torch.cuda.stream(side):
             fn()
         torch.cuda.current_stream().wait_stream(side)

@@ -194,7 +194,6 @@ static int wgrad_args(const frx_conv_desc* d, const void* x, const float* in_sca
   FRX_CHECK_ARG(xb < 0x80000000ull && yb < 0x80000000ull, "wgrad: tensors must stay below 2 GiB (32-bit buffer offsets)");
   a.xbytes = (unsigned)xb; a.ybytes = (unsigned)yb;
   g.wmode = d->stem ? WG_STEM : ((d->R == 1 && d->S == 1 && d->stride == 1) ? WG_POINTWISE : WG_GENERAL);
-  FRX_CHECK_ARG(!(pro_y && g.wmode != WG_POINTWISE && !(d->R == 1 && d->S == 1)), "conv_wgrad_bn: 1x1 convs only");
   a.variant = (g.bt == 128 ? WGV_BT128 : 0) | (g.wmode == WG_GENERAL ? WGV_GENERAL : 0) | (g.wmode == WG_STEM ? WGV_STEM : 0) |
               (in_scale ? WGV_PRO : 0) | (pro_y ? WGV_YPRO : 0);
   return FRX_OK;

@@ -203,9 +203,9 @@ class ResNet50Engine:
         shape = (c.Co, 7, 8, 4) if c.stem else (c.Co, c.k, c.k, c.Ci)
         return self.params[c.w_off:c.w_off + c.w_numel].view(shape)
 
-    def w_grad(self, c: ConvSpec):
+    def w_grad(self, c: ConvSpec, buf=None):
         shape = (c.Co, 7, 8, 4) if c.stem else (c.Co, c.k, c.k, c.Ci)
-        return self.grads[c.w_off:c.w_off + c.w_numel].view(shape)
+        return (self.grads if buf is None else buf)[c.w_off:c.w_off + c.w_numel].view(shape)
 
     def gamma(self, c, buf=None):
         return (self.params if buf is None else buf)[c.g_off:c.g_off + c.Co]

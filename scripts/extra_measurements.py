@@ -17,7 +17,7 @@ g = torch.Generator().manual_seed(0)
 host = [torch.randint(0, 256, (N, 112, 112, 3), dtype=torch.uint8, generator=g).pin_memory() for _ in range(4)]
 lab = torch.randint(0, C, (N,), generator=g).to(dev)
 dimg = torch.empty(N, 112, 112, 3, dtype=torch.uint8, device=dev)
-side = torch.cuda.Stream()
+side = torch.cuda.Stream(); side.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(side):
     eng.train_step(dimg, lab)
 torch.cuda.current_stream().wait_stream(side); torch.cuda.synchronize()

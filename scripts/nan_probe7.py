@@ -14,8 +14,11 @@ def make(grouped=True):
     images = torch.empty_like(batches[0][0]); labels = torch.empty_like(batches[0][1])
     eng.net.lr_dev.fill_(lr)
     return eng, images, labels
+FIXED_CAPTURE = False
 def capture(eng, images, labels):
     side = torch.cuda.Stream()
+    if FIXED_CAPTURE:
+        side.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(side):
         eng.train_step(images, labels)
     torch.cuda.current_stream().wait_stream(side)
@@ -53,6 +56,10 @@ print("quick check (graph, no sync):", quick, flush=True)
 if all(q[0] is None for q in quick):
     print("box looks clean"); sys.exit(0)
 print("=== BAD BOX: localising ===", flush=True)
+FIXED_CAPTURE = True
+print("graph_nosync with side.wait_stream(current) before the warm-up:", [run("graph_nosync")[:2] for _ in range(6)], flush=True)
+FIXED_CAPTURE = False
+print("graph_nosync as before:", [run("graph_nosync")[:2] for _ in range(3)], flush=True)
 for mode in ("graph_sync", "eager_nosync", "eager_sync", "graph_nosync"):
     for grouped in (True, False):
         print(f"{mode:13s} grouped={int(grouped)}:", [run(mode, grouped)[:2] for _ in range(3)], flush=True)
