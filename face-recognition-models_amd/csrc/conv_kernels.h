@@ -213,12 +213,14 @@ template <typename T> __device__ __forceinline__ float load_as_float(const void*
 template <typename T, int BM, int BN, int WM, int WN, int MODE, int PRO, int EPI, bool ADD>   // PRO: 0 none, 1 BN+ReLU, 2 BN-backward affine
 // waves per SIMD the register budget must allow: 3 where the kernel fits 168 registers without spilling (measured:
 // +10-20 % on the prologue-free variants), 2 for the BN-prologue variants (they spill 35-50 registers at 3)
-__global__ __launch_bounds__(256, (PRO == 0 && EPI != EPI_BNBWD_OUT && !ADD) ? 3 : 2) void k_igemm(ConvArgs a) {
+// (WM x WN = 4 waves; or 8 waves on a 128x128 tile for launches with too few tiles to give every SIMD two waves)
+__global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 4 : ((PRO == 0 && EPI != EPI_BNBWD_OUT && !ADD) ? 3 : 2)) void k_igemm(ConvArgs a) {
   constexpr int VEC = TT<T>::VEC, CE = TT<T>::CE;
+  constexpr int NT = 64 * WM * WN, RPP = NT / 4;       // threads; tile rows staged per pass (4 x 16-byte loads per row)
   constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 16, FN = WTN / 16;
-  constexpr int ALD = BM / 64, BLD = BN / 64;
+  constexpr int ALD = BM / RPP, BLD = BN / RPP;
   constexpr int STAGE = (BM + BN) * 64;
-  static_assert(WM * WN == 4 && WTM % 16 == 0 && WTN % 16 == 0, "bad wave tiling");
+  static_assert((WM * WN == 4 || WM * WN == 8) && WTM % 16 == 0 && WTN % 32 == 0 && ALD >= 1 && BLD >= 1, "bad wave tiling");
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   // BN scale/shift of the input channels live in LDS: fetching them from global memory at commit
   // time would be the NEWEST vector-memory op and force vmcnt(0), draining the prefetch ring.
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(256, (PRO == 0 && EPI != EPI_BNBWD_OUT && !ADD) ? 3
   bool rok[ALD];
 #pragma unroll
   for (int i = 0; i < ALD; ++i) {
-    const int m = m0 + srow + 64 * i;
+    const int m = m0 + srow + RPP * i;
     rok[i] = m < a.M;
     const int mm = rok[i] ? m : 0;
     int n, oh, ow;
@@ -283,12 +285,12 @@ __global__ __launch_bounds__(256, (PRO == 0 && EPI != EPI_BNBWD_OUT && !ADD) ? 3
   unsigned bvoff[BLD];
 #pragma unroll
   for (int i = 0; i < BLD; ++i) {
-    const int n = n0 + srow + 64 * i;                 // rows past Ncol read zeros; their outputs are never stored
+    const int n = n0 + srow + RPP * i;                // rows past Ncol read zeros; their outputs are never stored
     bvoff[i] = n < a.Ncol ? (unsigned)((n * ldw + chunk * VEC) * (int)sizeof(T)) : OOB;
   }
 
   if constexpr (PRO != 0) {
-    for (int c = tid; c < a.Kc; c += 256) {
+    for (int c = tid; c < a.Kc; c += NT) {
       s_scale[c] = a.in_scale[c]; s_shift[c] = a.in_shift[c];
       if constexpr (PRO == 2) s_gam[c] = a.pro_gam[c];
     }
@@ -380,12 +382,12 @@ __global__ __launch_bounds__(256, (PRO == 0 && EPI != EPI_BNBWD_OUT && !ADD) ? 3
         u32x4_t sv; sv[0] = v.x; sv[1] = v.y; sv[2] = v.z; sv[3] = v.w;
         __builtin_amdgcn_raw_buffer_store_b128(sv, rsrcDy, avoff[i] + (unsigned)(rc0[slot] * (int)sizeof(T)), 0, 0);
       }
-      const int row = srow + 64 * i;
+      const int row = srow + RPP * i;
       *reinterpret_cast<uint4*>(As + (row * 4 + (chunk ^ swz64(row))) * 16) = v;
     }
 #pragma unroll
     for (int i = 0; i < BLD; ++i) {
-      const int row = srow + 64 * i;
+      const int row = srow + RPP * i;
       *reinterpret_cast<uint4*>(Bs + (row * 4 + (chunk ^ swz64(row))) * 16) = rb[slot][i];
     }
   };
@@ -609,7 +611,7 @@ __global__ __launch_bounds__(256, (PRO == 0 && EPI != EPI_BNBWD_OUT && !ADD) ? 3
       red[(1 * WM + wm) * BN + col] = vq[0];
     }
     __syncthreads();
-    for (int t = tid; t < 2 * BN; t += 256) {
+    for (int t = tid; t < 2 * BN; t += NT) {
       const int which = t / BN, col = t % BN;
       float sum = 0.f;
 #pragma unroll

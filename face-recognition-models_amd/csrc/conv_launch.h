@@ -17,7 +17,9 @@ static inline TileCfg pick_tile(long M, int Ncol) {
   if (Ncol <= 64) return {128, 64};
   // measured per ResNet-50 shape (scripts/tile_sweep.py): the square 128x128 tile wins down to ~3/4 of a wave of
   // blocks (twice the MFMA work per staged byte and per prologue evaluation); below that the 64x64 tile's 4x
-  // block count beats the 128x64 one's 2x.
+  // block count beats the 128x64 one's 2x.  The 128x128 tile runs EIGHT waves (2x4, 64x32 each): half the
+  // staging work and accumulators per wave keep it under 128 registers, i.e. 16 waves per CU instead of 8 --
+  // 5-15 % on the forward convs, 3-10 % on the dgrads over four 64x64 waves.
   const long mt128 = (M + 127) / 128;
   if (mt128 * ((Ncol + 127) / 128) >= 192) return {128, 128};
   return {64, 64};
@@ -34,7 +36,7 @@ int launch_wgrad_grouped(hipStream_t st, int dtype, const WgradArgs* layers, con
 
 #define FRX_IGEMM_LAUNCH(T_, MODE_, PRO_, EPI_, ADD_)                                                                     \
   do {                                                                                                                    \
-    if (c.bm == 128 && c.bn == 128) hipLaunchKernelGGL((k_igemm<T_, 128, 128, 2, 2, MODE_, PRO_, EPI_, ADD_>), dim3(grid), dim3(256), 0, st, a); \
+    if (c.bm == 128 && c.bn == 128) hipLaunchKernelGGL((k_igemm<T_, 128, 128, 2, 4, MODE_, PRO_, EPI_, ADD_>), dim3(grid), dim3(512), 0, st, a); \
     else if (c.bm == 128 && c.bn == 64) hipLaunchKernelGGL((k_igemm<T_, 128, 64, 2, 2, MODE_, PRO_, EPI_, ADD_>), dim3(grid), dim3(256), 0, st, a); \
     else hipLaunchKernelGGL((k_igemm<T_, 64, 64, 2, 2, MODE_, PRO_, EPI_, ADD_>), dim3(grid), dim3(256), 0, st, a);       \
   } while (0)

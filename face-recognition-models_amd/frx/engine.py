@@ -265,11 +265,14 @@ class ResNet50Engine:
         self._prep_table = torch.tensor(rows, dtype=torch.int64, device=self.device)
         self._prep_blocks = blk
 
-    def sync_weights(self):
-        """fp32 master -> kernel-format copies (after an optimiser step or a state-dict load): one launch."""
-        m = self.w_master(self.stem)
-        m[:, :, 7, :] = 0          # the stem's 8th tap / 4th channel exist only as padding
-        m[..., 3] = 0
+    def sync_weights(self, pad=True):
+        """fp32 master -> kernel-format copies (after an optimiser step or a state-dict load): one launch.
+        pad=False skips re-zeroing the stem's padding slots: the engine's own SGD step cannot move them (their
+        gradient slots are never written, so weight decay and momentum act on exact zeros)."""
+        if pad:
+            m = self.w_master(self.stem)
+            m[:, :, 7, :] = 0          # the stem's 8th tap / 4th channel exist only as padding
+            m[..., 3] = 0
         if getattr(self, "_prep_table", None) is None:
             self._build_prep_table()
         ops.weight_prep_batched(self.dtype, self._prep_table, self.params, self._prep_blocks)
@@ -552,7 +555,7 @@ class ResNet50Engine:
         """lr=None: read the learning rate from self.lr_dev (graph-replay friendly)."""
         ops.sgd_step(self.params, self.grads, self.mom, 0.0 if lr is None else lr, momentum, weight_decay, grad_scale,
                      lr_dev=self.lr_dev if lr is None else None)
-        self.sync_weights()
+        self.sync_weights(pad=False)
 
     # ------------------------------------------------------------------ torchvision-compatible state dict
     def state_dict(self, prefix=""):
