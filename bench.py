@@ -79,6 +79,12 @@ def kernel_pass(eng, images, labels, steps=3):
         torch.cuda.synchronize()
         per_step.append([(label, flops, e0.elapsed_time(e1) * 1e-3, nbytes) for label, flops, e0, e1, nbytes in ops.PROFILER])
     ops.PROFILER = None
+    # work integrity: the step just run must have produced a weight gradient for EVERY conv layer (a kernel that
+    # silently does nothing makes the benchmark faster, not slower -- this is what would show it)
+    net = eng.net
+    dead = [c.name for c in net.convs if float(net.w_grad(c).abs().max()) == 0.0]
+    if dead:
+        raise SystemExit(f"bench: integrity check failed: zero weight gradient in {len(dead)} conv layers, e.g. {dead[:4]}")
     agg = {}
     for calls in zip(*per_step):
         label, flops, _, nbytes = calls[0]

@@ -476,6 +476,17 @@ __global__ __launch_bounds__(256) void k_norm_bwd_cols(const float* __restrict__
   }
 }
 
+// zero n4 float4s (D % 16 == 0 keeps every head buffer a multiple of 16 bytes)
+__global__ __launch_bounds__(256) void k_zero_f32(float* __restrict__ p, long n4) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n4) reinterpret_cast<float4*>(p)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+}
+
+__global__ __launch_bounds__(256) void k_copy_f32(const float* __restrict__ x, float* __restrict__ y, long n) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) y[i] = x[i];
+}
+
 // ------------------------------------------------------------------------------------------
 // Workspace carving
 // ------------------------------------------------------------------------------------------
@@ -607,8 +618,10 @@ extern "C" int frx_head_fwd_loss(int device, frx_stream_t stream, const frx_head
   hipLaunchKernelGGL(k_head_finalize, dim3(1), dim3(256), 0, st, (const float*)W.rowloss,
                      (const int32_t*)W.rowrank, d->N, loss, topk, (float*)nullptr);
   FRX_LAUNCH_CHECK();
-  if (lse) FRX_HIP(hipMemcpyAsync(lse, W.lse, sizeof(float) * d->N, hipMemcpyDeviceToDevice, st));
-  if (norms) FRX_HIP(hipMemcpyAsync(norms, W.xnorm, sizeof(float) * d->N, hipMemcpyDeviceToDevice, st));
+  // (kernels rather than hipMemcpyAsync: no memcpy / memset nodes in a captured step, see head_bwd_impl)
+  if (lse) hipLaunchKernelGGL(k_copy_f32, dim3(cdiv(d->N, 256)), dim3(256), 0, st, (const float*)W.lse, lse, (long)d->N);
+  if (norms) hipLaunchKernelGGL(k_copy_f32, dim3(cdiv(d->N, 256)), dim3(256), 0, st, (const float*)W.xnorm, norms, (long)d->N);
+  FRX_LAUNCH_CHECK();
   return FRX_OK;
 }
 
@@ -649,7 +662,10 @@ static int head_bwd_impl(int device, frx_stream_t stream, const frx_head_desc* d
   const bool cd = w_is_cd(d->kind);
   // dX^ [N,D] = dC [N,C] . W^   (K = C: split so the grid fills the chip)
   {
-    FRX_HIP(hipMemsetAsync(W.dxh, 0, sizeof(float) * (size_t)d->N * d->D, st));
+    // (a kernel, not hipMemsetAsync: inside a replayed hipGraph the memset NODE intermittently filled this buffer with
+    // a stale 32-bit pattern instead of 0 -- seen as dfeat ~1e8..1e34 on a fraction of the runs, graph mode only)
+    hipLaunchKernelGGL(k_zero_f32, dim3(cdiv((long)d->N * d->D / 4, 256)), dim3(256), 0, st, W.dxh, (long)d->N * d->D / 4);
+    FRX_LAUNCH_CHECK();
     GemmArgs g{};
     g.A = W.gbuf; g.lda = W.Cpad; g.a_mcontig = 0; g.a_kscale = W.winv;
     g.B = w; g.M = d->N; g.N = d->D; g.K = d->C;

@@ -252,6 +252,10 @@ def wgrad_group_plan(dtype, jobs):
     dev = jobs[0]["x"].device
     g = WgradGroup()
     g.table = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    # frx_wgrad_group_plan fills the table with a SYNCHRONOUS hipMemcpy, which is not ordered against torch's
+    # non-blocking streams: without this wait the zero-fill above can land after the copy and wipe the table
+    # (seen when the plan ran on a capture warm-up stream: the launch then did nothing, silently).
+    torch.cuda.current_stream(dev).synchronize()
     n = C.c_int(0)
     check(_lib.lib().frx_wgrad_group_plan(dev.index or 0, arr, len(jobs), _p(g.table), nbytes, C.byref(n)),
           "frx_wgrad_group_plan")

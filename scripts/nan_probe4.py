@@ -4,7 +4,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "face-recognition-models_amd"))
 import torch
 from frx import engine as E, ops
-N = 256; lr = 0.02; STEPS = 40
+N = 256; lr = 0.005; STEPS = 40
+p_ = torch.cuda.get_device_properties(0); print("uuid", getattr(p_, "uuid", None), flush=True)
 for trial in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
     eng = E.FaceEngine("arcface", 10575, N, dtype=ops.BF16, device="cuda:0", seed=0)
     g = torch.Generator().manual_seed(1234)
@@ -33,11 +34,13 @@ for trial in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
     watch += [("g_pool", net.g_pool), ("dy_stem", net.dy_stem), ("grads", net.grads), ("params", net.params),
               ("bn_mean", net.bn_mean), ("bn_invstd", net.bn_invstd), ("bn_scale", net.bn_scale), ("bn_shift", net.bn_shift)]
     flags = torch.ones(STEPS, len(watch), dtype=torch.bool, device="cuda:0")
+    amax = torch.zeros(STEPS, len(watch), device="cuda:0")
     for i in range(STEPS):
         feed(i)
         gr.replay()
         for k, (_, t) in enumerate(watch):
             flags[i, k] = torch.isfinite(t).all()
+            amax[i, k] = torch.nan_to_num(t.float(), nan=0.0, posinf=0.0, neginf=0.0).abs().max()
     torch.cuda.synchronize()
     f = flags.cpu()
     bad = (~f).any(1).nonzero().flatten().tolist()
@@ -48,5 +51,9 @@ for trial in range(int(sys.argv[1]) if len(sys.argv) > 1 else 6):
         print(f"trial {trial}: first non-finite at replay {i}: {len(names)} tensors, loss bad: {'loss' in names}, params bad: {'params' in names};"
               f" bad steps {bad[:10]}; at the last step {len(last)} bad, loss bad {'loss' in last}; final loss {out['loss'].item():.2f}", flush=True)
         print("    ", names[:6], "...", names[-8:])
+        am = amax.cpu()
+        for nm in ("grads", "params", "feats", "dfeat", "b15.out", "b0.dz3", "g_pool", "dy_stem", "bn_invstd", "bn_scale"):
+            k = [w[0] for w in watch].index(nm)
+            print(f"     |{nm}|max over the steps before: ", [f"{am[j, k].item():.3g}" for j in range(max(0, i - 4), i + 1)])
     else:
         print(f"trial {trial}: {STEPS} unsynchronised replays clean", flush=True)
