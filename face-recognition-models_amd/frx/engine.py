@@ -189,7 +189,7 @@ class ResNet50Engine:
         self.g_pool = torch.zeros_like(self.pool_out)        # gradient w.r.t. the max-pool output
         self.dy_stem = torch.zeros_like(self.stem.y)
         self.grouped_wgrad = os.environ.get("FRX_WGRAD_GROUPED", "1") != "0"
-        self._wg_groups = None                               # planned lazily (needs every buffer above)
+        self._wg_groups = None                               # planned at the end of __init__ (needs every buffer)
         self.dfeat_t = torch.zeros(N, FEATURE_DIM, dtype=self.tdt, device=dev)
         self.lr_dev = torch.zeros(1, device=dev)
         self.training = True
@@ -197,6 +197,8 @@ class ResNet50Engine:
         self.share = share
         if share is None:
             self.reset_parameters()
+        if self.grouped_wgrad:
+            self._plan_wgrad_groups()          # here, not at first use: planning synchronises, which a graph capture forbids
 
     # ------------------------------------------------------------------ parameter views
     def w_master(self, c: ConvSpec):
