@@ -165,17 +165,33 @@ __global__ __launch_bounds__(256) void k_row_norms(const float* __restrict__ a, 
   }
 }
 
-// column norms of a [D, C] matrix (CosFace / CurricularFace `kernel`): thread per column
+// column norms of a [D, C] matrix (CosFace / CurricularFace `kernel`).  64 columns x 4 row-lanes per block, 8
+// independent loads per lane in flight (one thread walking D rows of a column alone is D dependent round trips:
+// 206 us for the 174 MB of an 85 000-class head, ~6x the HBM time).
+constexpr int COLB = 64, COLR = 4, COLU = 8;
 __global__ __launch_bounds__(256) void k_col_norms(const float* __restrict__ a, int D, int C,
                                                    float* __restrict__ inv) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  __shared__ float red[COLR][COLB];
+  const int cl = threadIdx.x % COLB, rl = threadIdx.x / COLB;
+  const int c = blockIdx.x * COLB + cl;
   float s = 0.f;
-  for (int d = 0; d < D; ++d) {
-    const float v = a[(long)d * C + c];
-    s += v * v;
+  if (c < C) {
+    for (int d0 = rl; d0 < D; d0 += COLR * COLU) {
+      float v[COLU];
+#pragma unroll
+      for (int u = 0; u < COLU; ++u) { const int d = d0 + COLR * u; v[u] = d < D ? a[(long)d * C + c] : 0.f; }
+#pragma unroll
+      for (int u = 0; u < COLU; ++u) s += v[u] * v[u];
+    }
   }
-  inv[c] = 1.f / fmaxf(sqrtf(s), 1e-12f);
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < COLR; ++i) t += red[i][cl];
+    inv[c] = 1.f / fmaxf(sqrtf(t), 1e-12f);
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -458,21 +474,49 @@ __global__ __launch_bounds__(256) void k_norm_bwd_rows(const float* __restrict__
   }
 }
 
-// same for column vectors of a [D, C] matrix: thread per column
+// same for column vectors of a [D, C] matrix: 64 columns x 4 row-lanes per block (see k_col_norms)
 __global__ __launch_bounds__(256) void k_norm_bwd_cols(const float* __restrict__ a,
                                                        const float* __restrict__ dh,
                                                        const float* __restrict__ inv, int D, int C,
                                                        float* __restrict__ out, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
-  const float iv = inv[c];
+  __shared__ float red[COLR][COLB];
+  const int cl = threadIdx.x % COLB, rl = threadIdx.x / COLB;
+  const int c = blockIdx.x * COLB + cl;
+  const bool live = c < C;
+  const float iv = live ? inv[c] : 0.f;
+  float part = 0.f;
+  if (live) {
+    for (int d0 = rl; d0 < D; d0 += COLR * COLU) {
+      float va[COLU], vd[COLU];
+#pragma unroll
+      for (int u = 0; u < COLU; ++u) {
+        const int d = d0 + COLR * u;
+        const long i = (long)(d < D ? d : d0) * C + c;
+        va[u] = a[i]; vd[u] = d < D ? dh[i] : 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < COLU; ++u) part += va[u] * iv * vd[u];
+    }
+  }
+  red[rl][cl] = part;
+  __syncthreads();
   float dot = 0.f;
-  for (int d = 0; d < D; ++d) dot += a[(long)d * C + c] * iv * dh[(long)d * C + c];
-  for (int d = 0; d < D; ++d) {
-    const long i = (long)d * C + c;
-    float o = (dh[i] - a[i] * iv * dot) * iv;
-    if (accumulate) o += out[i];
-    out[i] = o;
+#pragma unroll
+  for (int i = 0; i < COLR; ++i) dot += red[i][cl];
+  if (!live) return;
+  for (int d0 = rl; d0 < D; d0 += COLR * COLU) {
+    float va[COLU], vd[COLU], vo[COLU];
+#pragma unroll
+    for (int u = 0; u < COLU; ++u) {
+      const int d = d0 + COLR * u;
+      const long i = (long)(d < D ? d : d0) * C + c;
+      va[u] = a[i]; vd[u] = dh[i]; vo[u] = accumulate ? out[i] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < COLU; ++u) {
+      const int d = d0 + COLR * u;
+      if (d < D) out[(long)d * C + c] = (vd[u] - va[u] * iv * dot) * iv + vo[u];
+    }
   }
 }
 
@@ -566,7 +610,7 @@ extern "C" int frx_head_fwd_cos(int device, frx_stream_t stream, const frx_head_
   if (w_is_cd(d->kind))
     hipLaunchKernelGGL(k_row_norms, dim3(cdiv(d->C, 4)), dim3(256), 0, st, w, d->C, d->D, W.winv, (float*)nullptr);
   else
-    hipLaunchKernelGGL(k_col_norms, dim3(cdiv(d->C, 256)), dim3(256), 0, st, w, d->D, d->C, W.winv);
+    hipLaunchKernelGGL(k_col_norms, dim3(cdiv(d->C, COLB)), dim3(256), 0, st, w, d->D, d->C, W.winv);
   FRX_LAUNCH_CHECK();
   GemmArgs g{};
   g.A = x; g.lda = d->D; g.a_mcontig = 0;
@@ -700,7 +744,7 @@ static int head_bwd_impl(int device, frx_stream_t stream, const frx_head_desc* d
     hipLaunchKernelGGL(k_norm_bwd_rows, dim3(cdiv(d->C, 4)), dim3(256), 0, st, w, (const float*)W.dwh,
                        (const float*)W.winv, (const float*)nullptr, d->C, d->D, dw, accumulate_dw);
   else
-    hipLaunchKernelGGL(k_norm_bwd_cols, dim3(cdiv(d->C, 256)), dim3(256), 0, st, w, (const float*)W.dwh,
+    hipLaunchKernelGGL(k_norm_bwd_cols, dim3(cdiv(d->C, COLB)), dim3(256), 0, st, w, (const float*)W.dwh,
                        (const float*)W.winv, d->D, d->C, dw, accumulate_dw);
   FRX_LAUNCH_CHECK();
   return FRX_OK;
