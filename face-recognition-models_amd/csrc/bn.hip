@@ -327,7 +327,10 @@ __global__ __launch_bounds__(256) void k_pool_fwd(int N, int H, int W, int C, co
   constexpr int V = Vec16<T>::N;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1, G = C / V;
   const long total = (long)N * Ho * Wo * G;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+  // XCD-contiguous index ranges (block b runs on XCD b % 8): the overlapping 3x3 windows of neighbouring rows are
+  // then fetched into ONE L2 instead of up to four (225 -> ~150 MB of HBM traffic for the backward)
+  const long chunk = (total + 7) / 8, lo = (long)(blockIdx.x & 7) * chunk, hi = lo + chunk < total ? lo + chunk : total;
+  for (long i = lo + (long)(blockIdx.x >> 3) * 256 + threadIdx.x; i < hi; i += (long)(gridDim.x >> 3) * 256) {
     const int g = (int)(i % G);
     long p = i / G;
     const int ow = (int)(p % Wo); p /= Wo;
@@ -373,7 +376,10 @@ __global__ __launch_bounds__(256) void k_pool_bwd(int N, int H, int W, int C, co
   constexpr int V = Vec16<T>::N;
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1, G = C / V;
   const long total = (long)N * H * W * G;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+  // XCD-contiguous index ranges (block b runs on XCD b % 8): the overlapping 3x3 windows of neighbouring rows are
+  // then fetched into ONE L2 instead of up to four (225 -> ~150 MB of HBM traffic for the backward)
+  const long chunk = (total + 7) / 8, lo = (long)(blockIdx.x & 7) * chunk, hi = lo + chunk < total ? lo + chunk : total;
+  for (long i = lo + (long)(blockIdx.x >> 3) * 256 + threadIdx.x; i < hi; i += (long)(gridDim.x >> 3) * 256) {
     const int g = (int)(i % G);
     long p = i / G;
     const int w = (int)(p % W); p /= W;
@@ -437,6 +443,13 @@ static inline int row_grid(long rows, int C, int V) {
   long b = (rows + (long)rpp * RU - 1) / ((long)rpp * RU);
   if (b > 256 * 16) b = 256 * 16;
   if (b < 1) b = 1;
+  return (int)b;
+}
+
+static inline int pool_grid(long work_items) {       // multiple of 8: the pool kernels split the index space per XCD
+  long b = (work_items + 255) / 256;
+  if (b > 256 * 16) b = 256 * 16;
+  b = (b + 7) / 8 * 8;
   return (int)b;
 }
 
@@ -571,10 +584,10 @@ extern "C" int frx_stem_pool_fwd(int device, frx_stream_t stream, int dtype, int
   FRX_ENTER(device);
   const long total = (long)N * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * C / FRX_VEC(dtype);
   if (dtype == FRX_BF16)
-    hipLaunchKernelGGL(k_pool_fwd<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, N, H, W, C,
+    hipLaunchKernelGGL(k_pool_fwd<bf16_t>, dim3(pool_grid(total)), dim3(256), 0, (hipStream_t)stream, N, H, W, C,
                        (const bf16_t*)y, scale, shift, (bf16_t*)out, argmax);
   else
-    hipLaunchKernelGGL(k_pool_fwd<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, N, H, W, C,
+    hipLaunchKernelGGL(k_pool_fwd<float>, dim3(pool_grid(total)), dim3(256), 0, (hipStream_t)stream, N, H, W, C,
                        (const float*)y, scale, shift, (float*)out, argmax);
   FRX_LAUNCH_CHECK();
   return FRX_OK;
@@ -587,10 +600,10 @@ extern "C" int frx_stem_pool_bwd(int device, frx_stream_t stream, int dtype, int
   FRX_ENTER(device);
   const long total = (long)N * H * W * C / FRX_VEC(dtype);
   if (dtype == FRX_BF16)
-    hipLaunchKernelGGL(k_pool_bwd<bf16_t>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, N, H, W, C,
+    hipLaunchKernelGGL(k_pool_bwd<bf16_t>, dim3(pool_grid(total)), dim3(256), 0, (hipStream_t)stream, N, H, W, C,
                        (const bf16_t*)dout, argmax, (bf16_t*)dpost);
   else
-    hipLaunchKernelGGL(k_pool_bwd<float>, dim3(ew_grid(total)), dim3(256), 0, (hipStream_t)stream, N, H, W, C,
+    hipLaunchKernelGGL(k_pool_bwd<float>, dim3(pool_grid(total)), dim3(256), 0, (hipStream_t)stream, N, H, W, C,
                        (const float*)dout, argmax, (float*)dpost);
   FRX_LAUNCH_CHECK();
   return FRX_OK;
