@@ -44,6 +44,7 @@ def library_path() -> str:
 _P = C.c_void_p
 _SIGS = {
     "frx_version": (C.c_int, []),
+    "frx_struct_sizes": (C.c_int, [C.POINTER(C.c_int64)]),
     "frx_last_error": (C.c_char_p, []),
     "frx_device_props": (C.c_int, [C.c_int, C.POINTER(C.c_int64)]),
     "frx_head_workspace_bytes": (C.c_size_t, [C.POINTER(HeadDesc)]),

@@ -42,6 +42,9 @@ enum frx_head_kind { FRX_ARC = 0, FRX_COS = 1, FRX_SPHERE = 2, FRX_CURR = 3 };
 
 /* ---------------------------------------------------------------- diagnostics */
 int frx_version(void);
+/* sizeof(frx_head_desc), sizeof(frx_conv_desc), sizeof(frx_dgrad_fuse), sizeof(frx_wgrad_job): lets a binding verify its
+ * own struct layouts (ctypes / cgo / JNI) against the library it loaded */
+int frx_struct_sizes(int64_t sizes[4]);
 const char* frx_last_error(void);
 /* props[0]=CU count, [1]=clock kHz, [2]=LDS bytes/CU, [3]=wavefront size, [4]=gcnArch is gfx950 (0/1) */
 int frx_device_props(int device, int64_t props[8]);

@@ -43,3 +43,12 @@ def test_product_does_not_import_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dp, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), f"{f} imports the oracle"
+
+
+def test_struct_layouts_match_the_library():
+    """the ctypes mirrors of the boundary structs have the sizes the C compiler gave them (padding included)"""
+    import ctypes as C
+    from frx import _lib
+    sizes = (C.c_int64 * 4)()
+    assert _lib.lib().frx_struct_sizes(sizes) == 0
+    assert list(sizes) == [C.sizeof(_lib.HeadDesc), C.sizeof(_lib.ConvDesc), C.sizeof(_lib.DgradFuse), C.sizeof(_lib.WgradJob)]
