@@ -143,7 +143,8 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_merge_fwd(long rows, int C, const T* __restrict__ y3,
                                                    const float* __restrict__ s3, const float* __restrict__ b3,
                                                    const T* __restrict__ idn, const float* __restrict__ sd,
-                                                   const float* __restrict__ bd, T* __restrict__ out) {
+                                                   const float* __restrict__ bd, T* __restrict__ out,
+                                                   uint8_t* __restrict__ mask) {
   constexpr int V = Vec16<T>::N;
   const RowWalk w(C, V);
   const long stride = (long)gridDim.x * w.rpp;
@@ -165,10 +166,16 @@ __global__ __launch_bounds__(256) void k_merge_fwd(long rows, int C, const T* __
       for (int u = 0; u < RU; ++u) {
         const long rr = r + u * stride;
         Vec16<T> o;
+        unsigned bits = 0;
 #pragma unroll
-        for (int j = 0; j < V; ++j)
+        for (int j = 0; j < V; ++j) {
           o.set(j, fmaxf(fmaf(a[u].get(j), ks[j], kb[j]) + fmaf(b[u].get(j), ds[j], db[j]), 0.f));
-        if (rr < rows) reinterpret_cast<uint4*>(out)[rr * w.groups + grp] = o.raw;
+          bits |= (o.get(j) > 0.f ? 1u : 0u) << j;      // of the ROUNDED output: what `out > 0` would see
+        }
+        if (rr < rows) {
+          reinterpret_cast<uint4*>(out)[rr * w.groups + grp] = o.raw;
+          if (mask) mask[rr * w.groups + grp] = (uint8_t)bits;
+        }
       }
     }
   }
@@ -492,9 +499,9 @@ extern "C" int frx_bn_eval_affine(int device, frx_stream_t stream, int C, const 
   return FRX_OK;
 }
 
-extern "C" int frx_block_merge_fwd(int device, frx_stream_t stream, int dtype, int64_t rows, int C, const void* y3,
-                                   const float* s3, const float* b3, const void* idn, const float* sd,
-                                   const float* bd, void* out) {
+static int merge_impl(int device, frx_stream_t stream, int dtype, int64_t rows, int C, const void* y3,
+                      const float* s3, const float* b3, const void* idn, const float* sd,
+                      const float* bd, void* out, uint8_t* mask) {
   FRX_DT_CHECK(dtype);
   FRX_CHECK_ARG(y3 && s3 && b3 && idn && out && rows > 0 && C % FRX_VEC(dtype) == 0, "block_merge_fwd: bad args");
   FRX_CHECK_ARG(frx_groups_ok(C / FRX_VEC(dtype)), "block_merge_fwd: C=%d must give a power-of-two number of 16-byte groups", C);
@@ -503,12 +510,25 @@ extern "C" int frx_block_merge_fwd(int device, frx_stream_t stream, int dtype, i
   const int grid = row_grid(rows, C, FRX_VEC(dtype));
   if (dtype == FRX_BF16)
     hipLaunchKernelGGL(k_merge_fwd<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (long)rows, C,
-                       (const bf16_t*)y3, s3, b3, (const bf16_t*)idn, sd, bd, (bf16_t*)out);
+                       (const bf16_t*)y3, s3, b3, (const bf16_t*)idn, sd, bd, (bf16_t*)out, mask);
   else
     hipLaunchKernelGGL(k_merge_fwd<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (long)rows, C,
-                       (const float*)y3, s3, b3, (const float*)idn, sd, bd, (float*)out);
+                       (const float*)y3, s3, b3, (const float*)idn, sd, bd, (float*)out, mask);
   FRX_LAUNCH_CHECK();
   return FRX_OK;
+}
+
+extern "C" int frx_block_merge_fwd(int device, frx_stream_t stream, int dtype, int64_t rows, int C, const void* y3,
+                                   const float* s3, const float* b3, const void* idn, const float* sd,
+                                   const float* bd, void* out) {
+  return merge_impl(device, stream, dtype, rows, C, y3, s3, b3, idn, sd, bd, out, nullptr);
+}
+
+extern "C" int frx_block_merge_fwd_mask(int device, frx_stream_t stream, int dtype, int64_t rows, int C, const void* y3,
+                                        const float* s3, const float* b3, const void* idn, const float* sd,
+                                        const float* bd, void* out, uint8_t* mask) {
+  FRX_CHECK_ARG(mask != nullptr, "block_merge_fwd_mask: mask is NULL");
+  return merge_impl(device, stream, dtype, rows, C, y3, s3, b3, idn, sd, bd, out, mask);
 }
 
 extern "C" int frx_bn_bwd_partial_rows(int64_t rows, int C) {

@@ -23,7 +23,7 @@ static int launch_igemm(hipStream_t st, ConvArgs a, int dtype) {
   a.tilesN = cdiv(a.Ncol, c.bn);
   const int grid = (int)round_up(a.tilesM, 8) * a.tilesN;
   int epi = EPI_PLAIN;
-  if (a.epi_bnbwd) epi = a.e_out ? EPI_BNBWD_OUT : EPI_BNBWD;
+  if (a.epi_bnbwd) epi = (a.e_out || a.e_bits) ? EPI_BNBWD_OUT : EPI_BNBWD;
   else if (a.stat_partial) epi = EPI_STATS;
   else if (a.out_f32 || a.bias) epi = EPI_FC;
   if (a.mode == MODE_STEM) return launch_igemm_stem(st, a, dtype, c, grid, epi);
@@ -134,8 +134,9 @@ static int dgrad_impl(int device, frx_stream_t stream, const frx_conv_desc* d, c
     }
     if (f->epi_y) {
       FRX_CHECK_ARG(f->epi_mean && f->epi_invstd && f->epi_partial, "conv_dgrad_bn: epilogue needs mean / invstd / partial");
-      FRX_CHECK_ARG(f->epi_out || (f->epi_scale && f->epi_shift), "conv_dgrad_bn: epilogue mask needs epi_out or scale/shift");
+      FRX_CHECK_ARG(f->epi_out || f->epi_out_bits || (f->epi_scale && f->epi_shift), "conv_dgrad_bn: epilogue mask needs epi_out(_bits) or scale/shift");
       a.epi_bnbwd = 1; a.e_y = f->epi_y; a.e_out = f->epi_out; a.e_scale = f->epi_scale; a.e_shift = f->epi_shift;
+      a.e_bits = (const unsigned char*)f->epi_out_bits;
       a.e_mean = f->epi_mean; a.e_invstd = f->epi_invstd; a.stat_partial = f->epi_partial;
     }
   }

@@ -66,6 +66,8 @@ struct ConvArgs {
   int epi_bnbwd;
   const void* e_y;        //   raw conv output of that BN layer, [M][Ncol]
   const void* e_out;      //   optional: block output -> mask = out > 0 (merge ReLU); else mask = e_scale*y+e_shift > 0
+  const unsigned char* e_bits;  // optional, instead of e_out: the same mask as one byte per 16-byte channel group (bit j =
+                          //   channel j of the group is > 0), written by frx_block_merge_fwd_mask: 1/16 of the bytes
   const float* e_scale; const float* e_shift; const float* e_mean; const float* e_invstd;
   int N, Hx, Wx, Kc;      // geometry of X (Kc = its channel count)
   int Ho, Wo;             // output spatial size; M = N*Ho*Wo
@@ -494,7 +496,10 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 4 : ((PRO == 0 && EPI 
   const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(a.Y, 0, ybytes, 0x00020000);
   const unsigned ebytes = (unsigned)a.M * (unsigned)a.Ncol * (unsigned)sizeof(T);
   const __amdgpu_buffer_rsrc_t rsrcEy = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>((EPI == EPI_BNBWD || EPI == EPI_BNBWD_OUT) ? a.e_y : a.Y), 0, ebytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrcEo = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(EPI == EPI_BNBWD_OUT ? a.e_out : a.Y), 0, ebytes, 0x00020000);
+  const bool ebits = EPI == EPI_BNBWD_OUT && a.e_bits != nullptr;          // block-uniform
+  const __amdgpu_buffer_rsrc_t rsrcEo = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<void*>(EPI == EPI_BNBWD_OUT ? (ebits ? (const void*)a.e_bits : a.e_out) : a.Y), 0,
+      ebits ? (unsigned)a.M * (unsigned)a.Ncol / (unsigned)VEC : ebytes, 0x00020000);
   const int mrow = m0 + wm * WTM + fr;                          // this lane's pixel row for fragment i = 0
   const int ncol0 = n0 + wn * WTN + 8 * fq;                     // first of its 8 channels for pair a2 = 0
   const unsigned elem0 = (unsigned)mrow * (unsigned)a.Ncol + (unsigned)ncol0;   // element index of (mrow, ncol0)
@@ -540,7 +545,19 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 4 : ((PRO == 0 && EPI 
       const int so_t = (int)(i * rstep * sizeof(T)), so_o = (int)(i * rstep * OSZ);
       if constexpr (ADD) buf_load8<OUT32 ? 4 : 2>(rsrcAdd, addvo[i] + 32u * a2 * OSZ, 0, av[i]);
       if constexpr (EPI == EPI_BNBWD || EPI == EPI_BNBWD_OUT) buf_load8<sizeof(T)>(rsrcEy, eoff * (unsigned)sizeof(T), so_t, yv[i]);
-      if constexpr (EPI == EPI_BNBWD_OUT) buf_load8<sizeof(T)>(rsrcEo, eoff * (unsigned)sizeof(T), so_t, ov[i]);
+      if constexpr (EPI == EPI_BNBWD_OUT) {
+        if (ebits) {        // this lane's 8 channels are 8 / VEC groups: 1 mask byte (bf16) or 2 (fp32); expand to +-1
+          const unsigned gidx = (eoff + (unsigned)i * rstep) / (unsigned)VEC;
+          unsigned m8;
+          if constexpr (VEC == 8) m8 = __builtin_amdgcn_raw_buffer_load_b8(rsrcEo, gidx, 0, 0);
+          else m8 = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rsrcEo, gidx, 0, 0) |
+                    ((unsigned)__builtin_amdgcn_raw_buffer_load_b8(rsrcEo, gidx + 1u, 0, 0) << 4);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) ov[i][e] = ((m8 >> e) & 1u) ? 1.f : 0.f;
+        } else {
+          buf_load8<sizeof(T)>(rsrcEo, eoff * (unsigned)sizeof(T), so_t, ov[i]);
+        }
+      }
     }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {

@@ -26,7 +26,7 @@ class ConvDesc(C.Structure):
 
 class DgradFuse(C.Structure):
     _fields_ = ([(n, C.c_void_p) for n in ("pro_y", "pro_coef", "epi_y", "epi_out", "epi_scale", "epi_shift",
-                                           "epi_mean", "epi_invstd", "epi_partial")]
+                                           "epi_mean", "epi_invstd", "epi_partial", "epi_out_bits")]
                 + [("addend_stride", C.c_int32), ("pro_dy_out", C.c_void_p)])
 
 
@@ -70,6 +70,7 @@ _SIGS = {
                                   _P, _P, _P, _P, _P, _P]),
     "frx_bn_eval_affine": (C.c_int, [C.c_int, _P, C.c_int, _P, _P, _P, _P, C.c_float, _P, _P]),
     "frx_block_merge_fwd": (C.c_int, [C.c_int, _P, C.c_int, C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
+    "frx_block_merge_fwd_mask": (C.c_int, [C.c_int, _P, C.c_int, C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "frx_bn_bwd_partial_rows": (C.c_int, [C.c_int64, C.c_int]),
     "frx_bn_bwd_reduce": (C.c_int, [C.c_int, _P, C.c_int, C.c_int64, C.c_int, _P, _P, _P, _P, _P, C.c_int,
                                     _P, _P, _P, _P]),

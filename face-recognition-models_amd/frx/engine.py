@@ -66,6 +66,7 @@ class BlockSpec:
     dy2: torch.Tensor = None     # gradient of conv2's raw output
     dyc: dict = None             # conv name -> copy of dy kept by its dgrad (where _keeps_dy says so)
     coefs: list = None           # BN-backward coefficients of bn3 / bn2 / bn1 / downsample
+    mask: torch.Tensor = None    # out > 0 as one byte per 16-byte channel group (the backward's merge-ReLU mask)
 
 
 def resnet50_specs(H=112):
@@ -165,6 +166,7 @@ class ResNet50Engine:
         self.pool_arg = torch.zeros(N, self.hpool, self.hpool, 64, dtype=torch.uint8, device=dev)
         for b in self.blocks:
             b.out = torch.zeros_like(b.conv3.y)
+            b.mask = torch.zeros(b.out.numel() // (8 if dtype == BF16 else 4), dtype=torch.uint8, device=dev)
             b.dz3 = torch.zeros_like(b.conv3.y)
             b.dy2 = torch.zeros_like(b.conv2.y)
             b.dyc = {c.name: torch.zeros_like(c.y) for c in (b.conv1, b.conv3, b.down) if c is not None and self._keeps_dy(c)}
@@ -189,6 +191,7 @@ class ResNet50Engine:
         self.g_pool = torch.zeros_like(self.pool_out)        # gradient w.r.t. the max-pool output
         self.dy_stem = torch.zeros_like(self.stem.y)
         self.grouped_wgrad = os.environ.get("FRX_WGRAD_GROUPED", "1") != "0"
+        self.mask_bits = os.environ.get("FRX_MASK_BITS", "1") != "0"
         self._wg_groups = None                               # planned at the end of __init__ (needs every buffer)
         self.dfeat_t = torch.zeros(N, FEATURE_DIM, dtype=self.tdt, device=dev)
         self.lr_dev = torch.zeros(1, device=dev)
@@ -336,10 +339,11 @@ class ResNet50Engine:
                 self._conv_bn(b.down, x, None)
                 ops.block_merge_fwd(dt, rows, b.conv3.Co, b.conv3.y, self._bn(self.bn_scale, b.conv3),
                                     self._bn(self.bn_shift, b.conv3), b.down.y, b.out,
-                                    sd=self._bn(self.bn_scale, b.down), bd=self._bn(self.bn_shift, b.down))
+                                    sd=self._bn(self.bn_scale, b.down), bd=self._bn(self.bn_shift, b.down),
+                                    mask=b.mask if (self.training and self.mask_bits) else None)
             else:
                 ops.block_merge_fwd(dt, rows, b.conv3.Co, b.conv3.y, self._bn(self.bn_scale, b.conv3),
-                                    self._bn(self.bn_shift, b.conv3), x, b.out)
+                                    self._bn(self.bn_shift, b.conv3), x, b.out, mask=b.mask if (self.training and self.mask_bits) else None)
             x = b.out
         hw = self.h_final * self.h_final
         ops.avgpool_fwd(dt, N, hw, 2048, x, self.pooled)
@@ -377,7 +381,9 @@ class ResNet50Engine:
         """keyword arguments of conv_dgrad_bn's epilogue for back-propagating through BN `c` (+ ReLU / merge)"""
         kw = dict(epi_y=c.y, epi_mean=self._bn(self.bn_mean, c), epi_invstd=self._bn(self.bn_invstd, c),
                   epi_partial=self.bwd_partial)
-        if out is not None:
+        if out is not None and out.dtype == torch.uint8:
+            kw["epi_out_bits"] = out       # the block's 1-bit-per-element mask: 1/16 of reading its bf16 output again
+        elif out is not None:
             kw["epi_out"] = out
         else:
             kw["epi_scale"], kw["epi_shift"] = self._bn(self.bn_scale, c), self._bn(self.bn_shift, c)
@@ -471,7 +477,7 @@ class ResNet50Engine:
             # conv1 (1x1): its dgrad writes the masked output gradient of the block below (or the pool's)
             if prev is not None:      # epilogue: merge-ReLU mask of the block below + its bn3 reduce
                 self._bwd_1x1(b, c1, dz1, C1, x_in, prev.dz3, addend=addend, addend_stride=add_stride,
-                              **self._epi(prev.conv3, out=prev.out))
+                              **self._epi(prev.conv3, out=prev.mask if self.mask_bits else prev.out))
                 npart = ops.conv_dgrad_stat_rows(c1.desc)
             else:
                 self._bwd_1x1(b, c1, dz1, C1, x_in, self.g_pool, addend=addend, addend_stride=add_stride)

@@ -280,17 +280,18 @@ def conv_dgrad_stat_rows(d):
 
 
 def conv_dgrad_bn(d, dz, w_crsk, dx, addend=None, pro_y=None, pro_coef=None, epi_y=None, epi_out=None, epi_scale=None,
-                  epi_shift=None, epi_mean=None, epi_invstd=None, epi_partial=None, pro_dy_out=None, addend_stride=0):
+                  epi_shift=None, epi_mean=None, epi_invstd=None, epi_partial=None, pro_dy_out=None, addend_stride=0,
+                  epi_out_bits=None):
     """dgrad with the BatchNorm backward fused in (prologue: dy = alpha*dz + beta*pro_y + gam; epilogue: mask +
     per-channel reduce of the produced gradient)."""
     f = _lib.DgradFuse(*[0 if t is None else t.data_ptr() for t in
-                         (pro_y, pro_coef, epi_y, epi_out, epi_scale, epi_shift, epi_mean, epi_invstd, epi_partial)],
+                         (pro_y, pro_coef, epi_y, epi_out, epi_scale, epi_shift, epi_mean, epi_invstd, epi_partial, epi_out_bits)],
                        int(addend_stride), 0 if pro_dy_out is None else pro_dy_out.data_ptr())
     bm, bn = _igemm_tile(d.N * d.Hi * d.Wi, d.Ci)
     _timed(f"k_igemm<{_dt_name(d.dtype)},{bm},{bn}>", conv_flops(d), dz, lambda: check(
         _lib.lib().frx_conv_dgrad_bn(_dev(dz), _stream(dz), C.byref(d), _p(dz), _p(w_crsk), _p(addend), _p(dx),
                                      C.byref(f)), "frx_conv_dgrad_bn"),
-        nbytes=conv_bytes(d, n_in=1 + (addend is not None) + (epi_y is not None) + (epi_out is not None),
+        nbytes=conv_bytes(d, n_in=1 + (addend is not None) + (epi_y is not None) + (epi_out is not None) + (epi_out_bits is not None) / 16,
                           n_out=1 + (pro_y is not None) + (pro_dy_out is not None)))
     return dx
 
@@ -315,9 +316,14 @@ def bn_eval_affine(gamma, beta, rmean, rvar, scale, shift, eps=1e-5):
                                         _p(rvar), eps, _p(scale), _p(shift)), "frx_bn_eval_affine")
 
 
-def block_merge_fwd(dtype, rows, Cc, y3, s3, b3, idn, out, sd=None, bd=None):
-    check(_lib.lib().frx_block_merge_fwd(_dev(y3), _stream(y3), dtype, rows, Cc, _p(y3), _p(s3), _p(b3), _p(idn),
-                                         _p(sd), _p(bd), _p(out)), "frx_block_merge_fwd")
+def block_merge_fwd(dtype, rows, Cc, y3, s3, b3, idn, out, sd=None, bd=None, mask=None):
+    """mask: optional uint8 [rows * Cc / V] (V = 8 bf16 / 4 fp32): the out > 0 bits, for conv_dgrad_bn(epi_out_bits=...)"""
+    if mask is None:
+        check(_lib.lib().frx_block_merge_fwd(_dev(y3), _stream(y3), dtype, rows, Cc, _p(y3), _p(s3), _p(b3), _p(idn),
+                                             _p(sd), _p(bd), _p(out)), "frx_block_merge_fwd")
+    else:
+        check(_lib.lib().frx_block_merge_fwd_mask(_dev(y3), _stream(y3), dtype, rows, Cc, _p(y3), _p(s3), _p(b3), _p(idn),
+                                                  _p(sd), _p(bd), _p(out), _p(mask)), "frx_block_merge_fwd_mask")
     return out
 
 

@@ -155,6 +155,8 @@ typedef struct frx_dgrad_fuse {
   const float* epi_mean;
   const float* epi_invstd;
   float* epi_partial;
+  const void* epi_out_bits;  /* optional, instead of epi_out: the merge-ReLU mask as written by frx_block_merge_fwd_mask
+                                (one byte per 16-byte channel group): the epilogue then reads 1/16 of the bytes */
   int32_t addend_stride;     /* 0 / 1: `addend` has dx's shape.  2: it is the COMPACT [N,ceil(Hi/2),ceil(Wi/2),Ci] input
                                 gradient of a stride-2 1x1 branch (computed as a stride-1 conv on the coarse grid) and is
                                 added at the even pixels: the zeros of the other three quarters are never materialised */
@@ -203,6 +205,11 @@ int frx_bn_eval_affine(int device, frx_stream_t stream, int C, const float* gamm
 int frx_block_merge_fwd(int device, frx_stream_t stream, int dtype, int64_t rows, int C, const void* y3,
                         const float* s3, const float* b3, const void* idn, const float* sd, const float* bd,
                         void* out);
+/* the same, also writing mask [rows * C / V] bytes, V = channels per 16-byte group (8 bf16 / 4 fp32): bit j of a byte =
+ * (channel j of that group > 0) -- the backward's ReLU mask at 1/16 of the block output's size */
+int frx_block_merge_fwd_mask(int device, frx_stream_t stream, int dtype, int64_t rows, int C, const void* y3,
+                             const float* s3, const float* b3, const void* idn, const float* sd, const float* bd,
+                             void* out, uint8_t* mask);
 /* BatchNorm backward in three steps.  dz = g*mask with mask = (out>0) if out given, else
  * (scale*y+shift>0) if relu, else 1.
  *   reduce   -> partial [frx_bn_bwd_partial_rows][2][C] = (sum dz, sum dz*xhat); optional dz_out

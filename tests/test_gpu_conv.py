@@ -193,6 +193,14 @@ def test_fused_bn_backward_in_dgrad_wgrad(dtype, shape, merge_mask):
     ops.conv_dgrad_bn(d, dz, wt, dz_out, addend=add, pro_y=y, pro_coef=coef, epi_y=ey, epi_out=eout, epi_scale=esc,
                       epi_shift=esh, epi_mean=emu, epi_invstd=eis, epi_partial=part, pro_dy_out=dy_side)
     _close(dz_out, dz_ref.float().cpu(), dtype, "fused dz")
+    if merge_mask:      # the same mask as one byte per 16-byte channel group (what frx_block_merge_fwd_mask writes)
+        V = 8 if dtype == 1 else 4
+        bits = ((eout.float() > 0).view(-1, V).to(torch.int32) << torch.arange(V, device=DEV, dtype=torch.int32)).sum(1).to(torch.uint8)
+        part_b = torch.zeros(prow, 2, Ci, device=DEV)
+        dz_b = torch.empty_like(dx_ref)
+        ops.conv_dgrad_bn(d, dz, wt, dz_b, addend=add, pro_y=y, pro_coef=coef, epi_y=ey, epi_out_bits=bits, epi_scale=esc,
+                          epi_shift=esh, epi_mean=emu, epi_invstd=eis, epi_partial=part_b)
+        assert torch.equal(dz_b, dz_out) and torch.equal(part_b, part), "bit mask and bf16 mask must give identical results"
     if dy_side is not None:
         assert torch.isfinite(dy_side.float()).all(), "side output has unwritten elements"
         _close(dy_side, dy.float().cpu(), dtype, "dy side output")
@@ -306,3 +314,21 @@ def test_grouped_wgrad_matches_per_layer(dtype):
     ops.wgrad_group_run(grp)            # accumulates like the per-layer calls
     for j, r in zip(jobs, refs):
         _close(j["dw"] * 0.5, r.cpu(), dtype, "grouped wgrad %s" % (tuple(r.shape),))
+
+
+@pytest.mark.parametrize("dtype", [0, 1], ids=["f32", "bf16"])
+def test_block_merge_mask_bits(dtype):
+    from frx import ops
+    rows, Cc = 37 * 49, 256
+    T = ops.TORCH_DT[dtype]
+    y3 = _mk(dtype, rows, Cc, seed=1).to(DEV); idn = _mk(dtype, rows, Cc, seed=2).to(DEV)
+    g = torch.Generator().manual_seed(3)
+    s3, b3 = (torch.rand(Cc, generator=g) + 0.5).to(DEV), (torch.randn(Cc, generator=g) * 0.3).to(DEV)
+    ref = torch.empty_like(y3); out = torch.empty_like(y3)
+    V = 8 if dtype == 1 else 4
+    mask = torch.zeros(rows * Cc // V, dtype=torch.uint8, device=DEV)
+    ops.block_merge_fwd(dtype, rows, Cc, y3, s3, b3, idn, ref)
+    ops.block_merge_fwd(dtype, rows, Cc, y3, s3, b3, idn, out, mask=mask)
+    assert torch.equal(out, ref)
+    want = ((ref.float() > 0).view(-1, V).to(torch.int32) << torch.arange(V, device=DEV, dtype=torch.int32)).sum(1).to(torch.uint8)
+    assert torch.equal(mask, want)
