@@ -340,25 +340,43 @@ __global__ __launch_bounds__(256) void k_head_rows(HeadConst h, const float* __r
   float zy, dummy, u;
   head_z<KIND>(cy, true, h, r, zy, dummy, u);
 
+  // four consecutive classes per thread and trip (16-byte loads; rows are Cpad-strided, Cpad % 64 == 0): a quarter
+  // of the dependent round trips of the one-float walk, which at C = 85 000 was the whole cost of this kernel
   float zmax = -INFINITY;
   int rank = 0;
-  for (int j = threadIdx.x; j < C; j += 256) {
-    const float cc = head_clamp<KIND>(crow[j]);
-    float z, d;
-    head_z<KIND>(cc, j == y, h, r, z, d, u);
-    const float cs = head_cos_s<KIND>(cc, h, r);
-    zmax = fmaxf(zmax, z);
-    rank += (cs > cos_s_y) ? 1 : 0;
-    if (cos_s_out) cos_s_out[(long)n * C + j] = cs;
-    if (logits_out) logits_out[(long)n * C + j] = z;
+  for (int j0 = threadIdx.x * 4; j0 < C; j0 += 1024) {
+    const float4 c4 = *reinterpret_cast<const float4*>(crow + j0);
+    const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = j0 + e;
+      if (j < C) {
+        const float cc = head_clamp<KIND>(cv[e]);
+        float z, d;
+        head_z<KIND>(cc, j == y, h, r, z, d, u);
+        const float cs = head_cos_s<KIND>(cc, h, r);
+        zmax = fmaxf(zmax, z);
+        rank += (cs > cos_s_y) ? 1 : 0;
+        if (cos_s_out) cos_s_out[(long)n * C + j] = cs;
+        if (logits_out) logits_out[(long)n * C + j] = z;
+      }
+    }
   }
   zmax = block_max256(zmax, sh);
   float se = 0.f;
-  for (int j = threadIdx.x; j < C; j += 256) {
-    const float cc = head_clamp<KIND>(crow[j]);
-    float z, d;
-    head_z<KIND>(cc, j == y, h, r, z, d, u);
-    se += expf(z - zmax);
+  for (int j0 = threadIdx.x * 4; j0 < C; j0 += 1024) {
+    const float4 c4 = *reinterpret_cast<const float4*>(crow + j0);
+    const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = j0 + e;
+      if (j < C) {
+        const float cc = head_clamp<KIND>(cv[e]);
+        float z, d;
+        head_z<KIND>(cc, j == y, h, r, z, d, u);
+        se += expf(z - zmax);
+      }
+    }
   }
   se = block_sum256(se, sh);
   rank = wave_sum_i(rank);
@@ -417,19 +435,27 @@ __global__ __launch_bounds__(256) void k_head_grad(HeadConst h, const float* __r
   const float gs = (gout ? *gout : 1.f) * inv_n;
   const float l = lse[n];
   float dnorm = 0.f;
-  for (int j = threadIdx.x; j < Cpad; j += 256) {
-    float out = 0.f;
-    if (j < C) {
-      const float craw = crow[j];
-      const float cc = head_clamp<KIND>(craw);
-      float z, d, u;
-      head_z<KIND>(cc, j == y, h, r, z, d, u);
-      // upstream gradient: mean-CE in closed form, or an arbitrary dL/dlogits supplied by autograd
-      const float g = dlogits ? dlogits[(long)n * C + j] : (expf(z - l) - (j == y ? 1.f : 0.f)) * gs;
-      out = head_pass<KIND>(craw) ? g * d : 0.f;
-      if (KIND == FRX_SPHERE) dnorm += g * u;
+  for (int j0 = threadIdx.x * 4; j0 < Cpad; j0 += 1024) {       // 16-byte loads / stores, as in k_head_rows
+    const float4 c4 = *reinterpret_cast<const float4*>(crow + j0);
+    const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
+    float ov[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int j = j0 + e;
+      float out = 0.f;
+      if (j < C) {
+        const float craw = cv[e];
+        const float cc = head_clamp<KIND>(craw);
+        float z, d, u;
+        head_z<KIND>(cc, j == y, h, r, z, d, u);
+        // upstream gradient: mean-CE in closed form, or an arbitrary dL/dlogits supplied by autograd
+        const float g = dlogits ? dlogits[(long)n * C + j] : (expf(z - l) - (j == y ? 1.f : 0.f)) * gs;
+        out = head_pass<KIND>(craw) ? g * d : 0.f;
+        if (KIND == FRX_SPHERE) dnorm += g * u;
+      }
+      ov[e] = out;
     }
-    grow[j] = out;
+    *reinterpret_cast<float4*>(grow + j0) = make_float4(ov[0], ov[1], ov[2], ov[3]);
   }
   if (KIND == FRX_SPHERE) {
     dnorm = block_sum256(dnorm, sh);
