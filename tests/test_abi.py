@@ -52,3 +52,25 @@ def test_struct_layouts_match_the_library():
     sizes = (C.c_int64 * 4)()
     assert _lib.lib().frx_struct_sizes(sizes) == 0
     assert list(sizes) == [C.sizeof(_lib.HeadDesc), C.sizeof(_lib.ConvDesc), C.sizeof(_lib.DgradFuse), C.sizeof(_lib.WgradJob)]
+
+
+def test_wgrad_group_planning_is_host_logic():
+    """frx_wgrad_group_bytes plans the persistent work list on the host: no GPU needed.  Pointers are only recorded."""
+    import ctypes as C
+    from frx import _lib
+    L = _lib.lib()
+
+    def job(dtype, N, H, Ci, Co, k, stride):
+        Ho = (H + 2 * (k // 2) - k) // stride + 1
+        d = _lib.ConvDesc(dtype, N, H, H, Ci, Co, k, k, stride, k // 2, Ho, Ho, 0)
+        return _lib.WgradJob(d, 0x1000, None, None, 0, 0x2000, None, None, 0x3000)
+
+    jobs = (_lib.WgradJob * 3)(job(1, 256, 7, 256, 1024, 1, 1), job(1, 256, 28, 64, 64, 3, 1), job(1, 256, 14, 256, 512, 1, 2))
+    nbytes = L.frx_wgrad_group_bytes(jobs, 3)
+    # layer 0: 16 tiles x 6 splits (392 chunks / 64), layer 1: 9 taps x 98 splits, layer 2: 8 tiles x 6 splits (392 chunks)
+    items = 16 * 6 + 9 * 98 + 8 * 6
+    assert nbytes >= 3 * 64 + items * 16 and nbytes < 4096 + (items + 8 * 8) * 16 + 3 * 512
+    bad = (_lib.WgradJob * 2)(job(1, 8, 7, 256, 256, 1, 1), job(0, 8, 7, 256, 256, 1, 1))
+    assert L.frx_wgrad_group_bytes(bad, 2) < 0 and b"dtype" in L.frx_last_error()
+    null = (_lib.WgradJob * 1)(_lib.WgradJob(jobs[0].d, None, None, None, 0, 0x2000, None, None, 0x3000))
+    assert L.frx_wgrad_group_bytes(null, 1) < 0
