@@ -111,3 +111,34 @@ def test_upper_gradients_are_final_after_the_first_backward_half():
     for c in eng.net.convs:
         assert eng.net.w_grad(c).abs().max().item() > 0.0, c.name
     assert torch.isfinite(g2).all()
+
+
+def test_graph_replay_stays_finite_unsynchronised():
+    """Regression guard for the replay-only failures of DESIGN.md section 8 (a memset node that filled with a stale
+    pattern; a plan table wiped after its copy): 40 back-to-back replays of the captured full-size step, no host
+    synchronisation in between, must keep the loss finite, the parameters small and every conv gradient non-zero."""
+    eng = _engine()
+    x, y = _batch(6)
+    eng.net.lr_dev.fill_(0.005)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        eng.train_step(x, y)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        out = eng.train_step(x, y)
+    trace = torch.zeros(40, device=DEV)
+    for i in range(40):
+        graph.replay()
+        trace[i].copy_(out["loss"].reshape(()))
+    torch.cuda.synchronize()
+    ls = trace.tolist()
+    assert all(np.isfinite(ls)), ls
+    assert ls[-1] < ls[0], ls                     # the same batch every replay: the loss must come down
+    assert eng.net.params.abs().max().item() < 50.0
+    for c in eng.net.convs:
+        g = eng.net.w_grad(c)
+        assert torch.isfinite(g).all() and g.abs().max().item() > 0.0, c.name
