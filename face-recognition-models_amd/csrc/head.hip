@@ -200,25 +200,37 @@ __global__ __launch_bounds__(256) void k_col_norms(const float* __restrict__ a, 
 struct HeadConst {
   int kind;
   float s, cos_m, sin_m, th, mm, m, lamb;
+  float p0, p1, p2, p3;   // per-kind parameters (frx_head_desc::p)
+  int flags;
 };
 
 struct RowCtx {   // per-row values
   float xnorm;    // SPHERE
   float t;        // CURR: EMA value (already updated)
-  float ty;       // CURR: clamped target cosine
-  float cm;       // CURR: cos(theta_y + m)
+  float ty;       // CURR / MV: clamped target cosine
+  float cm;       // CURR / MV: the row's mask threshold (cos(theta_y + m), or ty - m for MV 'am')
+  float p;        // ADA: margin scaler; ELASTIC: sampled margin; MAG: adaptive margin
+  float aux;      // MAG: d(margin)/d||x||  (slope, or 0 where the norm clamp is active)
 };
+
+constexpr float kPi = 3.14159265358979323846f;
+constexpr bool kind_is_mv(int k) { return k == FRX_MV_AM || k == FRX_MV_ARC; }
+constexpr bool kind_eps7(int k) { return kind_is_mv(k) || k == FRX_ELASTIC_ARC || k == FRX_ELASTIC_COS || k == FRX_MAG; }
 
 template <int KIND>
 __device__ __forceinline__ float head_clamp(float c) {
   if (KIND == FRX_ARC) return c;
   if (KIND == FRX_COS) return fminf(fmaxf(c, -1.f + 1e-4f), 1.f - 1e-4f);
+  if (KIND == FRX_ADA) return fminf(fmaxf(c, -1.f + 1e-3f), 1.f - 1e-3f);          // criterion.py:866
+  if (kind_eps7(KIND)) return fminf(fmaxf(c, -1.f + 1e-7f), 1.f - 1e-7f);          // :414, :997, :1108, :1261
   return fminf(fmaxf(c, -1.f), 1.f);
 }
 template <int KIND>
 __device__ __forceinline__ bool head_pass(float c) {  // torch clamp backward mask (inclusive)
   if (KIND == FRX_ARC) return true;
   if (KIND == FRX_COS) return c >= -1.f + 1e-4f && c <= 1.f - 1e-4f;
+  if (KIND == FRX_ADA) return c >= -1.f + 1e-3f && c <= 1.f - 1e-3f;
+  if (kind_eps7(KIND)) return c >= -1.f + 1e-7f && c <= 1.f - 1e-7f;
   return c >= -1.f && c <= 1.f;
 }
 // pre-margin output ("cos_s", first element of the reference's output list)
@@ -263,6 +275,77 @@ __device__ __forceinline__ void head_z(float cc, bool target, const HeadConst& h
       dzdc = r.xnorm;
     }
     z = u * r.xnorm;
+  } else if (kind_is_mv(KIND)) {   // criterion.py:420-441
+    if (target) {
+      if (KIND == FRX_MV_AM) {
+        z = (r.ty > h.m ? r.ty - h.m : r.ty) * h.s;
+        dzdc = h.s;
+      } else if (r.ty > 0.f) {
+        z = r.cm * h.s;
+        dzdc = h.s * (h.cos_m + h.sin_m * r.ty / sqrtf(1.f - r.ty * r.ty + 1e-9f));
+      } else {
+        z = r.ty * h.s;
+        dzdc = h.s;
+      }
+    } else if (cc > r.cm) {           // mis-classified vector: re-weighted
+      z = (h.p0 * cc + (h.p0 - 1.f)) * h.s;
+      dzdc = h.s * h.p0;
+    } else {
+      z = cc * h.s;
+      dzdc = h.s;
+    }
+  } else if (KIND == FRX_ADA) {       // criterion.py:886-899; non-target entries pass through acos/cos unchanged
+    if (target) {
+      const float theta = acosf(cc);
+      const float raw = theta - h.m * r.p;
+      const float tm = fminf(fmaxf(raw, 1e-3f), kPi - 1e-3f);
+      z = (cosf(tm) - (h.m + h.m * r.p)) * h.s;
+      dzdc = (raw >= 1e-3f && raw <= kPi - 1e-3f) ? h.s * sinf(tm) * rsqrtf(1.f - cc * cc) : 0.f;
+    } else {
+      z = cc * h.s;
+      dzdc = h.s;
+    }
+  } else if (KIND == FRX_ELASTIC_ARC) {   // criterion.py:1125-1131
+    if (target) {
+      const float raw = acosf(cc) + r.p;
+      const float tm = fminf(fmaxf(raw, 0.f), kPi);
+      z = cosf(tm) * h.s;
+      dzdc = (raw >= 0.f && raw <= kPi) ? h.s * sinf(tm) * rsqrtf(1.f - cc * cc) : 0.f;
+    } else {
+      z = cc * h.s;
+      dzdc = h.s;
+    }
+  } else if (KIND == FRX_ELASTIC_COS) {   // criterion.py:1013-1014
+    z = (target ? cc - r.p : cc) * h.s;
+    dzdc = h.s;
+  } else if (KIND == FRX_MAG) {           // criterion.py:1264-1284; u = dz/d(margin) feeds the norm gradient
+    if (target) {
+      const float cm_ = cosf(r.p), sm_ = sinf(r.p);
+      const float sinth = sqrtf(1.f - cc * cc + 1e-9f);
+      const float ctm = cc * cm_ - sinth * sm_;
+      bool margin_on;
+      float zoff = cc, uoff = 0.f;
+      if (h.flags & 1) {
+        margin_on = cc > 0.f;
+      } else {
+        const float cpm = cosf(kPi - r.p), spm = sinf(kPi - r.p);
+        margin_on = cc > cpm;
+        zoff = cc - spm * r.p;
+        uoff = cpm * r.p - spm;
+      }
+      if (margin_on) {
+        z = ctm * h.s;
+        dzdc = h.s * (cm_ + sm_ * cc / sinth);
+        u = h.s * (-cc * sm_ - sinth * cm_);
+      } else {
+        z = zoff * h.s;
+        dzdc = h.s;
+        u = h.s * uoff;
+      }
+    } else {
+      z = cc * h.s;
+      dzdc = h.s;
+    }
   } else {  // CURR
     if (target) {
       if (r.ty > h.th) {
@@ -305,16 +388,68 @@ __global__ void k_curr_t_update(float* t, const float* ty_sum, float inv_count, 
 }
 
 __device__ __forceinline__ RowCtx make_row_ctx(int kind, int n, const HeadConst& h, const float* xnorm,
-                                               const float* ty, const float* state_t) {
+                                               const float* ty, const float* state_t, const float* rowp) {
   RowCtx r;
   r.xnorm = xnorm[n];
-  r.t = 0.f; r.ty = 0.f; r.cm = 0.f;
+  r.t = 0.f; r.ty = 0.f; r.cm = 0.f; r.p = 0.f; r.aux = 0.f;
   if (kind == FRX_CURR) {
     r.t = *state_t;
     r.ty = ty[n];
     r.cm = r.ty * h.cos_m - sqrtf(1.f - r.ty * r.ty) * h.sin_m;
+  } else if (kind == FRX_MV_AM) {
+    r.ty = ty[n];
+    r.cm = r.ty - h.m;                                                           // criterion.py:424
+  } else if (kind == FRX_MV_ARC) {
+    r.ty = ty[n];
+    r.cm = r.ty * h.cos_m - sqrtf(1.f - r.ty * r.ty + 1e-9f) * h.sin_m;           // :427-428
+  } else if (kind == FRX_ADA || kind == FRX_ELASTIC_ARC || kind == FRX_ELASTIC_COS) {
+    r.p = rowp[n];
+  } else if (kind == FRX_MAG) {
+    r.p = rowp[n];
+    r.aux = (r.xnorm >= h.p2 && r.xnorm <= h.p3) ? (h.p1 - h.p0) / (h.p3 - h.p2) : 0.f;
   }
   return r;
+}
+
+// Per-row parameters that depend on the batch of feature norms (one block; N is a batch size).
+//   ADA: margin scaler from the EMA of the batch mean / unbiased std of the clamped norms (criterion.py:869-880)
+//   MAG: clamped norm, adaptive margin, loss_g (criterion.py:1229-1249)
+template <int KIND>
+__global__ __launch_bounds__(256) void k_head_rowparam(HeadConst h, const float* __restrict__ xnorm, int N,
+                                                       float* __restrict__ state, float* __restrict__ rowp,
+                                                       float* __restrict__ xn_out, float* __restrict__ lossg) {
+  __shared__ float sh[4];
+  if (KIND == FRX_ADA) {
+    float part = 0.f;
+    for (int n = threadIdx.x; n < N; n += 256) part += fminf(fmaxf(xnorm[n], 0.001f), 100.f);
+    const float mean = block_sum256(part, sh) / (float)N;
+    __syncthreads();
+    part = 0.f;
+    for (int n = threadIdx.x; n < N; n += 256) {
+      const float dlt = fminf(fmaxf(xnorm[n], 0.001f), 100.f) - mean;
+      part += dlt * dlt;
+    }
+    const float sd = sqrtf(block_sum256(part, sh) / (float)(N - 1));
+    const float bm = mean * h.p1 + (1.f - h.p1) * state[0];
+    const float bs = sd * h.p1 + (1.f - h.p1) * state[1];
+    __syncthreads();                       // every thread has read the old state
+    if (threadIdx.x == 0) { state[0] = bm; state[1] = bs; }
+    for (int n = threadIdx.x; n < N; n += 256) {
+      const float safe = fminf(fmaxf(xnorm[n], 0.001f), 100.f);
+      rowp[n] = fminf(fmaxf((safe - bm) / (bs + 1e-3f) * h.p0, -1.f), 1.f);
+    }
+  } else {  // MAG
+    float part = 0.f;
+    const float slope = (h.p1 - h.p0) / (h.p3 - h.p2);
+    for (int n = threadIdx.x; n < N; n += 256) {
+      const float xn = fminf(fmaxf(xnorm[n], h.p2), h.p3);
+      xn_out[n] = xn;
+      rowp[n] = slope * (xn - h.p2) + h.p0;
+      part += 1.f / (h.p3 * h.p3) * xn + 1.f / xn;
+    }
+    const float tot = block_sum256(part, sh);
+    if (threadIdx.x == 0) *lossg = tot / (float)N;
+  }
 }
 
 // Forward row sweep: one 256-thread block per sample.
@@ -324,6 +459,7 @@ __global__ __launch_bounds__(256) void k_head_rows(HeadConst h, const float* __r
                                                    const float* __restrict__ xnorm,
                                                    const float* __restrict__ ty,
                                                    const float* __restrict__ state_t,
+                                                   const float* __restrict__ rowp,
                                                    float* __restrict__ cos_s_out,
                                                    float* __restrict__ logits_out,
                                                    float* __restrict__ lse_out,
@@ -334,7 +470,7 @@ __global__ __launch_bounds__(256) void k_head_rows(HeadConst h, const float* __r
   const int n = blockIdx.x;
   const int y = (int)labels[n];
   const float* crow = cbuf + (long)n * ldc;
-  const RowCtx r = make_row_ctx(KIND, n, h, xnorm, ty, state_t);
+  const RowCtx r = make_row_ctx(KIND, n, h, xnorm, ty, state_t, rowp);
   const float cy = head_clamp<KIND>(crow[y]);
   const float cos_s_y = head_cos_s<KIND>(cy, h, r);
   float zy, dummy, u;
@@ -422,6 +558,7 @@ __global__ __launch_bounds__(256) void k_head_grad(HeadConst h, const float* __r
                                                    const float* __restrict__ xnorm,
                                                    const float* __restrict__ ty,
                                                    const float* __restrict__ state_t,
+                                                   const float* __restrict__ rowp,
                                                    const float* __restrict__ lse,
                                                    const float* __restrict__ gout, float inv_n,
                                                    const float* __restrict__ dlogits,
@@ -431,7 +568,7 @@ __global__ __launch_bounds__(256) void k_head_grad(HeadConst h, const float* __r
   const int y = (int)labels[n];
   const float* crow = cbuf + (long)n * Cpad;
   float* grow = gbuf + (long)n * Cpad;
-  const RowCtx r = make_row_ctx(KIND, n, h, xnorm, ty, state_t);
+  const RowCtx r = make_row_ctx(KIND, n, h, xnorm, ty, state_t, rowp);
   const float gs = (gout ? *gout : 1.f) * inv_n;
   const float l = lse[n];
   float dnorm = 0.f;
@@ -452,14 +589,21 @@ __global__ __launch_bounds__(256) void k_head_grad(HeadConst h, const float* __r
         const float g = dlogits ? dlogits[(long)n * C + j] : (expf(z - l) - (j == y ? 1.f : 0.f)) * gs;
         out = head_pass<KIND>(craw) ? g * d : 0.f;
         if (KIND == FRX_SPHERE) dnorm += g * u;
+        if (KIND == FRX_MAG && j == y) dnorm += g * u * r.aux;      // through the adaptive margin (criterion.py:1264)
       }
       ov[e] = out;
     }
     *reinterpret_cast<float4*>(grow + j0) = make_float4(ov[0], ov[1], ov[2], ov[3]);
   }
-  if (KIND == FRX_SPHERE) {
+  if (KIND == FRX_SPHERE || KIND == FRX_MAG) {
     dnorm = block_sum256(dnorm, sh);
-    if (threadIdx.x == 0) dn[n] = dnorm;
+    if (threadIdx.x == 0) {
+      if (KIND == FRX_MAG && !dlogits && r.xnorm >= h.p2 && r.xnorm <= h.p3) {        // + lambda_g * d loss_g / d||x||  (criterion.py:1235-1239)
+        const float xn = r.xnorm;                               // clamp inactive here, so x_norm == ||x||
+        dnorm += h.lamb * gs * (1.f / (h.p3 * h.p3) - 1.f / (xn * xn));
+      }
+      dn[n] = dnorm;
+    }
   }
 }
 
@@ -561,7 +705,7 @@ __global__ __launch_bounds__(256) void k_copy_f32(const float* __restrict__ x, f
 // Workspace carving
 // ------------------------------------------------------------------------------------------
 struct HeadWs {
-  float *xinv, *xnorm, *winv, *ty, *tysum, *rowloss, *lse, *dn, *cbuf, *gbuf, *dxh, *dwh;
+  float *xinv, *xnorm, *winv, *ty, *tysum, *rowloss, *lse, *dn, *rowp, *xn, *lossg, *cbuf, *gbuf, *dxh, *dwh;
   int32_t* rowrank;
   int Cpad, Npad;
   size_t bytes;
@@ -581,6 +725,7 @@ static HeadWs carve(const frx_head_desc* d, void* base) {
   w.xinv = take(w.Npad); w.xnorm = take(w.Npad); w.winv = take(w.Cpad); w.ty = take(w.Npad);
   w.tysum = take(64); w.rowloss = take(w.Npad); w.lse = take(w.Npad); w.dn = take(w.Npad);
   w.rowrank = (int32_t*)take(w.Npad);
+  w.rowp = take(w.Npad); w.xn = take(w.Npad); w.lossg = take(64);
   w.cbuf = take((size_t)d->N * w.Cpad);
   w.gbuf = take((size_t)d->N * w.Cpad);
   w.dxh = take((size_t)d->N * d->D);
@@ -591,10 +736,13 @@ static HeadWs carve(const frx_head_desc* d, void* base) {
 
 static int check_desc(const frx_head_desc* d) {
   FRX_CHECK_ARG(d != nullptr, "head desc is NULL");
-  FRX_CHECK_ARG(d->kind >= FRX_ARC && d->kind <= FRX_CURR, "unknown head kind %d", d->kind);
+  FRX_CHECK_ARG(d->kind >= FRX_ARC && d->kind <= FRX_MAG, "unknown head kind %d", d->kind);
   FRX_CHECK_ARG(d->N > 0 && d->C > 0 && d->D > 0, "head dims must be positive (N=%d D=%d C=%d)", d->N, d->D, d->C);
   FRX_CHECK_ARG(d->D % 16 == 0, "head feature dim D=%d must be a multiple of 16", d->D);
   FRX_CHECK_ARG(d->kind != FRX_SPHERE || d->m == 2.f, "SphereFace supports m=2 only (config.py:17), got %g", (double)d->m);
+  FRX_CHECK_ARG(d->kind != FRX_MAG || (d->p[3] > d->p[2] && d->p[2] > 0.f), "MagFace needs 0 < l_a < u_a (got %g, %g)",
+                (double)d->p[2], (double)d->p[3]);
+  FRX_CHECK_ARG(d->kind != FRX_ADA || d->N > 1, "AdaFace's batch std needs N > 1");
   return FRX_OK;
 }
 
@@ -608,10 +756,34 @@ static HeadConst make_const(const frx_head_desc* d) {
   h.th = (float)cos(M_PI - (double)d->m);
   h.mm = (float)(sin(M_PI - (double)d->m) * (double)d->m);
   h.lamb = d->lamb;
+  h.p0 = d->p[0]; h.p1 = d->p[1]; h.p2 = d->p[2]; h.p3 = d->p[3];
+  h.flags = d->flags;
   return h;
 }
 
-static bool w_is_cd(int kind) { return kind == FRX_ARC || kind == FRX_SPHERE; }
+static bool w_is_cd(int kind) { return kind == FRX_ARC || kind == FRX_SPHERE || kind == FRX_MV_AM || kind == FRX_MV_ARC; }
+static bool needs_state(int kind) {
+  return kind == FRX_CURR || kind == FRX_ADA || kind == FRX_ELASTIC_ARC || kind == FRX_ELASTIC_COS;
+}
+static const char* state_what(int kind) {
+  return kind == FRX_CURR ? "CurricularFace needs the `t` buffer"
+       : kind == FRX_ADA  ? "AdaFace needs its [batch_mean, batch_std] state"
+                          : "the elastic heads need this step's per-row margins";
+}
+// expands M(KIND) for the runtime kind
+#define FRX_KIND_SWITCH(kind, M)                          \
+  switch (kind) {                                         \
+    case FRX_ARC: M(FRX_ARC); break;                      \
+    case FRX_COS: M(FRX_COS); break;                      \
+    case FRX_SPHERE: M(FRX_SPHERE); break;                \
+    case FRX_CURR: M(FRX_CURR); break;                    \
+    case FRX_MV_AM: M(FRX_MV_AM); break;                  \
+    case FRX_MV_ARC: M(FRX_MV_ARC); break;                \
+    case FRX_ADA: M(FRX_ADA); break;                      \
+    case FRX_ELASTIC_ARC: M(FRX_ELASTIC_ARC); break;      \
+    case FRX_ELASTIC_COS: M(FRX_ELASTIC_COS); break;      \
+    default: M(FRX_MAG); break;                           \
+  }
 
 }  // namespace frx
 
@@ -645,12 +817,9 @@ extern "C" int frx_head_fwd_cos(int device, frx_stream_t stream, const frx_head_
   g.C = W.cbuf; g.ldc = W.Cpad; g.row_scale = W.xinv; g.col_scale = W.winv;
   if (int rc = launch_gemm(st, g, 1)) return rc;
   float* tys = ty_sum_out ? ty_sum_out : W.tysum;
-  switch (d->kind) {
-    case FRX_ARC: hipLaunchKernelGGL(k_head_ty<FRX_ARC>, dim3(1), dim3(256), 0, st, W.cbuf, d->N, (long)W.Cpad, labels, W.ty, tys); break;
-    case FRX_COS: hipLaunchKernelGGL(k_head_ty<FRX_COS>, dim3(1), dim3(256), 0, st, W.cbuf, d->N, (long)W.Cpad, labels, W.ty, tys); break;
-    case FRX_SPHERE: hipLaunchKernelGGL(k_head_ty<FRX_SPHERE>, dim3(1), dim3(256), 0, st, W.cbuf, d->N, (long)W.Cpad, labels, W.ty, tys); break;
-    default: hipLaunchKernelGGL(k_head_ty<FRX_CURR>, dim3(1), dim3(256), 0, st, W.cbuf, d->N, (long)W.Cpad, labels, W.ty, tys); break;
-  }
+#define FRX_TY(K) hipLaunchKernelGGL(k_head_ty<K>, dim3(1), dim3(256), 0, st, W.cbuf, d->N, (long)W.Cpad, labels, W.ty, tys)
+  FRX_KIND_SWITCH(d->kind, FRX_TY)
+#undef FRX_TY
   FRX_LAUNCH_CHECK();
   return FRX_OK;
 }
@@ -661,7 +830,7 @@ extern "C" int frx_head_fwd_loss(int device, frx_stream_t stream, const frx_head
                                  float* norms, float* loss, float* lse, int32_t* topk) {
   if (int rc = check_desc(d)) return rc;
   FRX_CHECK_ARG(labels && ws, "head_fwd_loss: NULL pointer");
-  FRX_CHECK_ARG(d->kind != FRX_CURR || state_t, "CurricularFace needs the `t` buffer");
+  FRX_CHECK_ARG(!needs_state(d->kind) || state_t, "%s", state_what(d->kind));
   FRX_ENTER(device);
   hipStream_t st = (hipStream_t)stream;
   HeadWs W = carve(d, ws);
@@ -673,16 +842,17 @@ extern "C" int frx_head_fwd_loss(int device, frx_stream_t stream, const frx_head
     hipLaunchKernelGGL(k_curr_t_update, dim3(1), dim3(64), 0, st, state_t, src, (float)(1.0 / cnt), d->momentum);
     FRX_LAUNCH_CHECK();
   }
+  if (d->kind == FRX_ADA)
+    hipLaunchKernelGGL(k_head_rowparam<FRX_ADA>, dim3(1), dim3(256), 0, st, h, (const float*)W.xnorm, d->N, state_t, W.rowp, W.xn, W.lossg);
+  if (d->kind == FRX_MAG)
+    hipLaunchKernelGGL(k_head_rowparam<FRX_MAG>, dim3(1), dim3(256), 0, st, h, (const float*)W.xnorm, d->N, state_t, W.rowp, W.xn, W.lossg);
+  FRX_LAUNCH_CHECK();
+  const float* rowp = (d->kind == FRX_ELASTIC_ARC || d->kind == FRX_ELASTIC_COS) ? (const float*)state_t : (const float*)W.rowp;
 #define FRX_ROWS(K)                                                                                   \
   hipLaunchKernelGGL(k_head_rows<K>, dim3(d->N), dim3(256), 0, st, h, (const float*)W.cbuf, d->C,     \
                      (long)W.Cpad, labels, (const float*)W.xnorm, (const float*)W.ty,                 \
-                     (const float*)state_t, cos_s, logits, W.lse, W.rowloss, W.rowrank)
-  switch (d->kind) {
-    case FRX_ARC: FRX_ROWS(FRX_ARC); break;
-    case FRX_COS: FRX_ROWS(FRX_COS); break;
-    case FRX_SPHERE: FRX_ROWS(FRX_SPHERE); break;
-    default: FRX_ROWS(FRX_CURR); break;
-  }
+                     (const float*)state_t, rowp, cos_s, logits, W.lse, W.rowloss, W.rowrank)
+  FRX_KIND_SWITCH(d->kind, FRX_ROWS)
 #undef FRX_ROWS
   FRX_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_head_finalize, dim3(1), dim3(256), 0, st, (const float*)W.rowloss,
@@ -690,7 +860,31 @@ extern "C" int frx_head_fwd_loss(int device, frx_stream_t stream, const frx_head
   FRX_LAUNCH_CHECK();
   // (kernels rather than hipMemcpyAsync: no memcpy / memset nodes in a captured step, see head_bwd_impl)
   if (lse) hipLaunchKernelGGL(k_copy_f32, dim3(cdiv(d->N, 256)), dim3(256), 0, st, (const float*)W.lse, lse, (long)d->N);
-  if (norms) hipLaunchKernelGGL(k_copy_f32, dim3(cdiv(d->N, 256)), dim3(256), 0, st, (const float*)W.xnorm, norms, (long)d->N);
+  if (norms) hipLaunchKernelGGL(k_copy_f32, dim3(cdiv(d->N, 256)), dim3(256), 0, st,
+                                (const float*)(d->kind == FRX_MAG ? W.xn : W.xnorm), norms, (long)d->N);
+  FRX_LAUNCH_CHECK();
+  return FRX_OK;
+}
+
+__global__ void k_head_aux(int kind, const float* __restrict__ lossg, const float* __restrict__ rowp, int N,
+                           float* __restrict__ loss_g_out, float* __restrict__ rowp_out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i == 0 && loss_g_out) *loss_g_out = kind == FRX_MAG ? *lossg : 0.f;
+  if (rowp_out && i < N) rowp_out[i] = rowp ? rowp[i] : 0.f;
+}
+
+extern "C" int frx_head_aux(int device, frx_stream_t stream, const frx_head_desc* d, const float* state_t, void* ws,
+                            size_t ws_bytes, float* loss_g, float* row_param) {
+  if (int rc = check_desc(d)) return rc;
+  FRX_CHECK_ARG(ws, "head_aux: NULL workspace");
+  FRX_ENTER(device);
+  HeadWs W = carve(d, ws);
+  if (ws_bytes < W.bytes) { set_error("head workspace too small: %zu < %zu", ws_bytes, W.bytes); return FRX_ERR_WORKSPACE; }
+  const bool elastic = d->kind == FRX_ELASTIC_ARC || d->kind == FRX_ELASTIC_COS;
+  FRX_CHECK_ARG(!elastic || !row_param || state_t, "%s", state_what(d->kind));
+  const float* rowp = elastic ? state_t : (d->kind == FRX_ADA || d->kind == FRX_MAG) ? (const float*)W.rowp : nullptr;
+  hipLaunchKernelGGL(k_head_aux, dim3(cdiv(d->N, 256)), dim3(256), 0, (hipStream_t)stream, (int)d->kind,
+                     (const float*)W.lossg, rowp, d->N, loss_g, row_param);
   FRX_LAUNCH_CHECK();
   return FRX_OK;
 }
@@ -710,23 +904,19 @@ static int head_bwd_impl(int device, frx_stream_t stream, const frx_head_desc* d
                          float* dw, int accumulate_dw) {
   if (int rc = check_desc(d)) return rc;
   FRX_CHECK_ARG(x && w && labels && ws && dx && dw, "head_bwd: NULL pointer");
-  FRX_CHECK_ARG(d->kind != FRX_CURR || state_t, "CurricularFace needs the `t` buffer");
+  FRX_CHECK_ARG(!needs_state(d->kind) || state_t, "%s", state_what(d->kind));
   FRX_ENTER(device);
   hipStream_t st = (hipStream_t)stream;
   HeadWs W = carve(d, ws);
   if (ws_bytes < W.bytes) { set_error("head workspace too small: %zu < %zu", ws_bytes, W.bytes); return FRX_ERR_WORKSPACE; }
   HeadConst h = make_const(d);
   const float inv_n = 1.f / (float)d->N;
+  const float* rowp = (d->kind == FRX_ELASTIC_ARC || d->kind == FRX_ELASTIC_COS) ? state_t : (const float*)W.rowp;
 #define FRX_GRAD(K)                                                                                  \
   hipLaunchKernelGGL(k_head_grad<K>, dim3(d->N), dim3(256), 0, st, h, (const float*)W.cbuf, d->C,    \
-                     W.Cpad, labels, (const float*)W.xnorm, (const float*)W.ty, state_t,             \
+                     W.Cpad, labels, (const float*)W.xnorm, (const float*)W.ty, state_t, rowp,       \
                      (const float*)W.lse, gout, inv_n, dlogits, W.gbuf, W.dn)
-  switch (d->kind) {
-    case FRX_ARC: FRX_GRAD(FRX_ARC); break;
-    case FRX_COS: FRX_GRAD(FRX_COS); break;
-    case FRX_SPHERE: FRX_GRAD(FRX_SPHERE); break;
-    default: FRX_GRAD(FRX_CURR); break;
-  }
+  FRX_KIND_SWITCH(d->kind, FRX_GRAD)
 #undef FRX_GRAD
   FRX_LAUNCH_CHECK();
   const bool cd = w_is_cd(d->kind);
@@ -747,7 +937,7 @@ static int head_bwd_impl(int device, frx_stream_t stream, const frx_head_desc* d
     if (int rc = launch_gemm(st, g, ksplit)) return rc;
   }
   hipLaunchKernelGGL(k_norm_bwd_rows, dim3(cdiv(d->N, 4)), dim3(256), 0, st, x, (const float*)W.dxh,
-                     (const float*)W.xinv, d->kind == FRX_SPHERE ? (const float*)W.dn : (const float*)nullptr,
+                     (const float*)W.xinv, (d->kind == FRX_SPHERE || d->kind == FRX_MAG) ? (const float*)W.dn : (const float*)nullptr,
                      d->N, d->D, dx, 0);
   FRX_LAUNCH_CHECK();
   // dW^ = dC^T . X^  in the weight's own layout

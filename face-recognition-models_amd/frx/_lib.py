@@ -16,7 +16,8 @@ class FrxError(RuntimeError):
 
 class HeadDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("N", C.c_int32), ("D", C.c_int32), ("C", C.c_int32),
-                ("s", C.c_float), ("m", C.c_float), ("momentum", C.c_float), ("lamb", C.c_float)]
+                ("s", C.c_float), ("m", C.c_float), ("momentum", C.c_float), ("lamb", C.c_float),
+                ("p", C.c_float * 4), ("flags", C.c_int32), ("reserved", C.c_int32)]
 
 
 class ConvDesc(C.Structure):
@@ -55,6 +56,7 @@ _SIGS = {
                                _P, _P, _P, _P, _P, _P]),
     "frx_head_bwd": (C.c_int, [C.c_int, _P, C.POINTER(HeadDesc), _P, _P, _P, _P, _P, _P, C.c_size_t,
                                _P, _P, C.c_int]),
+    "frx_head_aux": (C.c_int, [C.c_int, _P, C.POINTER(HeadDesc), _P, _P, C.c_size_t, _P, _P]),
     "frx_conv_stat_rows": (C.c_int, [C.POINTER(ConvDesc)]),
     "frx_stem_padded_dims": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "frx_conv_fwd": (C.c_int, [C.c_int, _P, C.POINTER(ConvDesc), _P, _P, _P, _P, C.c_int, _P, _P, C.c_int, _P]),

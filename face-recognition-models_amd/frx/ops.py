@@ -10,6 +10,8 @@ from . import _lib
 from ._lib import FrxError, HeadDesc, check
 
 ARC, COS, SPHERE, CURR = 0, 1, 2, 3
+MV_AM, MV_ARC, ADA, ELASTIC_ARC, ELASTIC_COS, MAG = 4, 5, 6, 7, 8, 9       # include/frx.h frx_head_kind
+W_CD_KINDS = (ARC, SPHERE, MV_AM, MV_ARC)       # heads whose parameter is `weight` [C, D]; the others hold `kernel` [D, C]
 
 # Optional per-launch timing (bench.py roofline leg): when PROFILER is a list, the GEMM-class entry
 # points bracket their launch with events on the current stream and append
@@ -71,8 +73,12 @@ def _chk(t, dtype, name):
 class HeadContext:
     """Descriptor + workspace of one head instance (one per model; reused every step)."""
 
-    def __init__(self, kind, N, D, C_, s, m, momentum=0.01, device=None):
-        self.desc = HeadDesc(kind, N, D, C_, s, m, momentum, 0.0)
+    def __init__(self, kind, N, D, C_, s, m, momentum=0.01, device=None, p=(0.0, 0.0, 0.0, 0.0), flags=0, lambda_g=0.0):
+        """p / flags: per-kind parameters of frx_head_desc (MV: mv_weight; ADA: h, t_alpha; MAG: l_margin, u_margin,
+        l_a, u_a and flags bit 0 = easy_margin).  lambda_g: MagFace's loss_g weight for the fused backward."""
+        p = tuple(float(v) for v in p) + (0.0,) * (4 - len(p))
+        self.desc = HeadDesc(kind, N, D, C_, s, m, momentum, float(lambda_g) if kind == MAG else 0.0,
+                             (C.c_float * 4)(*p), int(flags), 0)
         nbytes = _lib.lib().frx_head_workspace_bytes(C.byref(self.desc))
         if nbytes == 0:
             raise FrxError("head descriptor rejected: " + _lib.lib().frx_last_error().decode())
@@ -94,7 +100,8 @@ def head_forward(ctx: HeadContext, x, w, labels, state_t=None, lamb=0.0, want_lo
     if tuple(x.shape) != (N, D) or labels.numel() != N or w.numel() != D * Cc:
         raise FrxError(f"head_forward: shapes x{tuple(x.shape)} w{tuple(w.shape)} labels{tuple(labels.shape)} "
                        f"do not match the context (N={N}, D={D}, C={Cc})")
-    ctx.desc.lamb = float(lamb)
+    if ctx.desc.kind == SPHERE:
+        ctx.desc.lamb = float(lamb)
     dev, st = _dev(x), _stream(x)
     o = dict(loss=torch.empty(1, device=x.device), topk=torch.empty(2, dtype=torch.int32, device=x.device),
              norms=torch.empty(N, device=x.device), lse=torch.empty(N, device=x.device),
@@ -115,6 +122,11 @@ def head_forward(ctx: HeadContext, x, w, labels, state_t=None, lamb=0.0, want_lo
         check(L.frx_head_fwd_loss(dev, st, C.byref(ctx.desc), _p(labels), _p(state_t), _p(tys), int(count),
                                   _p(ctx.ws), ctx.nbytes, _p(o["cos_s"]), _p(o["logits"]), _p(o["norms"]),
                                   _p(o["loss"]), _p(o["lse"]), _p(o["topk"])), "frx_head_fwd_loss")
+    if ctx.desc.kind in (ADA, ELASTIC_ARC, ELASTIC_COS, MAG):
+        o["loss_g"] = torch.empty(1, device=x.device)
+        o["row_param"] = torch.empty(N, device=x.device)
+        check(L.frx_head_aux(dev, st, C.byref(ctx.desc), _p(state_t), _p(ctx.ws), ctx.nbytes, _p(o["loss_g"]),
+                             _p(o["row_param"])), "frx_head_aux")
     return o
 
 

@@ -37,8 +37,11 @@ enum frx_status {
 
 enum frx_dtype { FRX_F32 = 0, FRX_BF16 = 1 };
 
-/* head kinds: utils/criterion.py ArcFace:232, CosFace:137, SphereFace:12, CurricularFace:491 */
-enum frx_head_kind { FRX_ARC = 0, FRX_COS = 1, FRX_SPHERE = 2, FRX_CURR = 3 };
+/* head kinds (main_code/utils/criterion.py): ArcFace:232, CosFace:137, SphereFace:12, CurricularFace:491, and the
+ * SURVEY 8(f)-3 widening: MV_Softmax:327 ('am' / 'arc' margin types), AdaFace:795, ElasticArcFace:1054,
+ * ElasticCosFace:951, MagFace:1178 */
+enum frx_head_kind { FRX_ARC = 0, FRX_COS = 1, FRX_SPHERE = 2, FRX_CURR = 3,
+                     FRX_MV_AM = 4, FRX_MV_ARC = 5, FRX_ADA = 6, FRX_ELASTIC_ARC = 7, FRX_ELASTIC_COS = 8, FRX_MAG = 9 };
 
 /* ---------------------------------------------------------------- diagnostics */
 int frx_version(void);
@@ -61,17 +64,30 @@ int frx_device_props(int device, int64_t props[8]);
 typedef struct frx_head_desc {
   int32_t kind;      /* frx_head_kind */
   int32_t N, D, C;   /* D % 16 == 0 */
-  float s, m;        /* scale / margin (config.py:16-37); SPHERE ignores s, m must be 2 */
+  float s, m;        /* scale / margin (config.py:16-70); SPHERE ignores s, m must be 2; ELASTIC / MAG ignore m */
   float momentum;    /* CURR EMA momentum (config.py:37) */
-  float lamb;        /* SPHERE annealing lambda for THIS forward (criterion.py:58-60; host state) */
+  float lamb;        /* SPHERE: annealing lambda for THIS forward (criterion.py:58-60; host state)
+                        MAG:    lambda_g, the weight of loss_g in the total loss (model_utils.py:180) -- used by
+                                frx_head_bwd only (frx_head_bwd_dlogits leaves loss_g to the caller's autograd) */
+  float p[4];        /* MV_*: p[0] = mv_weight (criterion.py:341)
+                        ADA:  p[0] = h, p[1] = t_alpha (criterion.py:805-807)
+                        MAG:  p[0] = l_margin, p[1] = u_margin, p[2] = l_a, p[3] = u_a (criterion.py:1188-1191) */
+  int32_t flags;     /* MAG: bit 0 = easy_margin (criterion.py:1187) */
+  int32_t reserved;
 } frx_head_desc;
+
+/* Per-kind meaning of the `state_t` argument of the calls below (device floats owned by the caller):
+ *   CURR          [1]  the `t` buffer (criterion.py:517), updated in place before use (:570-573)
+ *   ADA           [2]  batch_mean, batch_std (criterion.py:838-839), EMA-updated in place before use (:873-877)
+ *   ELASTIC_*     [N]  this step's per-row margins, already sampled and clamped by the caller
+ *                      (torch.normal + clamp, criterion.py:1002-1004 / 1113-1115; read only)
+ *   other kinds   may be NULL */
 
 size_t frx_head_workspace_bytes(const frx_head_desc* d);
 
 /* Forward.  The workspace keeps what backward needs (cosines, lse, inverse norms).
  *   labels   [N] int64
- *   state_t  [1] float, CURR's `t` buffer (criterion.py:517), updated in place before use (:570-573);
- *            may be NULL for other kinds
+ *   state_t  per-kind head state, see the table above (CURR's `t`, ADA's batch statistics, ELASTIC's margins)
  *   ty_sum   optional [1] float: when non-NULL the batch mean of the target cosine used in the
  *            EMA is ty_sum[0]/ty_count instead of the local mean (data-parallel: the caller
  *            all-reduces it between frx_head_fwd_cos and frx_head_fwd_loss)
@@ -86,6 +102,12 @@ int frx_head_fwd_loss(int device, frx_stream_t stream, const frx_head_desc* d, c
                       float* state_t, const float* ty_sum, int64_t ty_count, void* ws, size_t ws_bytes,
                       float* cos_s, float* logits, float* norms, float* loss, float* lse,
                       int32_t* topk);
+/* After frx_head_fwd_loss: loss_g [1] (MAG: mean(x_norm / u_a^2 + 1 / x_norm), criterion.py:1235-1239; 0 for other
+ * kinds) and, optionally, the per-row parameter the epilogue used, row_param [N]: ADA margin_scaler (:879-880), MAG
+ * ada_margin (:1229-1233), ELASTIC_* the margins passed in; zeros otherwise.  For MAG the `norms` output of
+ * frx_head_fwd_loss is the clamped x_norm the reference returns (:1246,1283). */
+int frx_head_aux(int device, frx_stream_t stream, const frx_head_desc* d, const float* state_t, void* ws,
+                 size_t ws_bytes, float* loss_g, float* row_param);
 /* both phases back to back (single GPU) */
 int frx_head_fwd(int device, frx_stream_t stream, const frx_head_desc* d, const float* x,
                  const float* w, const int64_t* labels, float* state_t, void* ws, size_t ws_bytes,

@@ -8,9 +8,14 @@ Follows the reference (paths relative to /root/reference/main_code):
   CosFace        utils/criterion.py:162-197   (ctor :141-154)
   SphereFace     utils/criterion.py:57-107    (ctor :17-49)
   CurricularFace utils/criterion.py:527-587   (ctor :496-519)
+  MV_Softmax     utils/criterion.py:388-450   (ctor :334-377; margin types 'am' and 'arc')
+  AdaFace        utils/criterion.py:848-907   (ctor :802-841)
+  ElasticArcFace utils/criterion.py:1089-1145 (ctor :1061-1083; plus=False)
+  ElasticCosFace utils/criterion.py:982-1021  (ctor :955-976; plus=False)
+  MagFace        utils/criterion.py:1241-1291 (ctor :1185-1222)
   CE             utils/model_utils.py:556,179 (nn.CrossEntropyLoss, mean)
   accuracy       utils/metrics.py:3-16
-Pinned by tests/golden/heads_*.npz (generated from the reference import).
+Pinned by tests/golden/heads_*.npz (generated from the reference import: make_golden.py, make_golden_heads2.py).
 """
 from __future__ import annotations
 
@@ -20,7 +25,9 @@ from dataclasses import dataclass, field
 import numpy as np
 
 ARC, COS, SPHERE, CURR = 0, 1, 2, 3
-KIND_NAMES = {ARC: "arcface", COS: "cosface", SPHERE: "sphereface", CURR: "curricular"}
+MV_AM, MV_ARC, ADA, ELASTIC_ARC, ELASTIC_COS, MAG = 4, 5, 6, 7, 8, 9
+KIND_NAMES = {ARC: "arcface", COS: "cosface", SPHERE: "sphereface", CURR: "curricular", MV_AM: "mv_am", MV_ARC: "mv_arc",
+              ADA: "adaface", ELASTIC_ARC: "elastic_arc", ELASTIC_COS: "elastic_cos", MAG: "magface"}
 
 NORM_EPS = 1e-12  # F.normalize default eps
 
@@ -31,6 +38,8 @@ class HeadState:
     iter: int = 0            # SphereFace.iter        (criterion.py:33,58)
     lamb: float = 0.0        # SphereFace.lamb        (criterion.py:60)
     t: float = 0.0           # CurricularFace.t buffer (criterion.py:517,572)
+    batch_mean: float = 20.0   # AdaFace buffers (criterion.py:838-839)
+    batch_std: float = 100.0
 
 
 @dataclass
@@ -44,6 +53,14 @@ class HeadHyper:
     gamma: float = 0.12
     power: float = 1.0
     lambda_min: float = 5.0
+    mv_weight: float = 1.12  # MV_Softmax (config.py:30)
+    h: float = 0.333         # AdaFace (config.py:49-50)
+    t_alpha: float = 0.99
+    l_margin: float = 0.45   # MagFace (config.py:66-70)
+    u_margin: float = 0.8
+    l_a: float = 10.0
+    u_a: float = 110.0
+    easy_margin: bool = False
 
     @staticmethod
     def default(kind: int) -> "HeadHyper":
@@ -56,13 +73,23 @@ class HeadHyper:
             return HeadHyper(SPHERE, s=1.0, m=2)  # S_sphere is unused by the reference
         if kind == CURR:
             return HeadHyper(CURR, s=64.0, m=0.5, momentum=0.01)
+        if kind in (MV_AM, MV_ARC):                     # config.py:29-32
+            return HeadHyper(kind, s=32.0, m=0.35, mv_weight=1.12)
+        if kind == ADA:                                  # config.py:47-50
+            return HeadHyper(ADA, s=64.0, m=0.4, h=0.333, t_alpha=0.99)
+        if kind == ELASTIC_ARC:                          # config.py:53-56 (the margin itself is sampled per row)
+            return HeadHyper(ELASTIC_ARC, s=64.0, m=0.5)
+        if kind == ELASTIC_COS:                          # config.py:59-62
+            return HeadHyper(ELASTIC_COS, s=64.0, m=0.35)
+        if kind == MAG:                                  # config.py:65-70
+            return HeadHyper(MAG, s=64.0, m=0.0)
         raise ValueError(kind)
 
 
 def weight_is_cd(kind: int) -> bool:
     """True when the class weight is stored [C, D] (ArcFace/SphereFace 'weight'),
     False when stored [D, C] (CosFace/CurricularFace 'kernel').  SURVEY H7."""
-    return kind in (ARC, SPHERE)
+    return kind in (ARC, SPHERE, MV_AM, MV_ARC)
 
 
 @dataclass
@@ -85,11 +112,14 @@ def _normalize_rows(a, dt):
 
 
 def head_forward_backward(kind, x, w, labels, hyper: HeadHyper, state: HeadState,
-                          dtype=np.float32, need_grad=True) -> HeadOut:
+                          dtype=np.float32, need_grad=True, row_margin=None, lambda_g=0.0) -> HeadOut:
     """One training-mode forward of the head + mean CE + its analytic backward.
 
-    x [N,D]; w [C,D] (ARC/SPHERE) or [D,C] (COS/CURR); labels [N] int.
+    x [N,D]; w [C,D] (ARC/SPHERE/MV) or [D,C] (the others); labels [N] int.
     Mutates `state` exactly as the reference forward does.
+    row_margin [N]: the elastic heads' sampled (and clamped) margins -- the reference draws them with torch.normal
+    inside forward (criterion.py:1002-1004, 1113-1115); here they are an input.
+    lambda_g: MagFace only; dx is the gradient of  CE + lambda_g * loss_g  (model_utils.py:180); `loss` stays the CE.
     """
     dt = np.dtype(dtype).type
     x = np.asarray(x, dtype=dtype)
@@ -172,6 +202,106 @@ def head_forward_backward(kind, x, w, labels, hyper: HeadHyper, state: HeadState
         dtar = np.where(ty > th, cos_m + sin_m * ty / sin_t, dt(1))
         dzdc = dt(hyper.s) * np.where(onehot > 0, np.broadcast_to(dtar, c.shape), dnon)
         extra.update(t=state.t)
+    elif kind in (MV_AM, MV_ARC):
+        lo, hi = dt(-1) + dt(1e-7), dt(1) - dt(1e-7)
+        c = np.clip(c_raw, lo, hi)                                 # :414
+        ty = c[rows, labels][:, None]                              # :418
+        if kind == MV_AM:
+            final_t = np.where(ty > dt(hyper.m), ty - dt(hyper.m), ty)      # :422-424
+            thr = ty - dt(hyper.m)
+            dtar = np.ones_like(ty)
+        else:
+            cos_m, sin_m = dt(math.cos(hyper.m)), dt(math.sin(hyper.m))
+            sin_t = np.sqrt(dt(1.0) - ty * ty + dt(1e-9))          # :428
+            thr = ty * cos_m - sin_t * sin_m                       # :429
+            final_t = np.where(ty > 0, thr, ty)                    # :430
+            dtar = np.where(ty > 0, cos_m + sin_m * ty / sin_t, dt(1))
+        mask = c > thr                                             # :425 / :431
+        mvw = dt(hyper.mv_weight)
+        zc = np.where(mask, mvw * c + (mvw - dt(1.0)), c)          # :434-436
+        zc[rows, labels] = final_t[:, 0]                           # :440
+        z = zc * dt(hyper.s)
+        cos_s = c * dt(hyper.s)
+        pass_clamp = (c_raw >= lo) & (c_raw <= hi)
+        dnon = np.where(mask, mvw, dt(1))
+        dzdc = dt(hyper.s) * np.where(onehot > 0, np.broadcast_to(dtar, c.shape), dnon)
+    elif kind == ADA:
+        eps = dt(1e-3)
+        lo, hi = dt(-1) + eps, dt(1) - eps
+        c = np.clip(c_raw, lo, hi)                                 # :866
+        safe = np.clip(xnorm, dt(0.001), dt(100))                  # :870
+        mean, std = safe.mean(dtype=dtype), safe.std(ddof=1, dtype=dtype)     # :873-874 (unbiased)
+        ta = dt(hyper.t_alpha)
+        state.batch_mean = float(mean * ta + (dt(1) - ta) * dt(state.batch_mean))   # :875-876
+        state.batch_std = float(std * ta + (dt(1) - ta) * dt(state.batch_std))
+        ms = (safe - dt(state.batch_mean)) / (dt(state.batch_std) + eps)     # :878
+        ms = np.clip(ms * dt(hyper.h), dt(-1), dt(1))              # :879
+        theta = np.arccos(c)                                       # :887
+        raw = theta + onehot * (dt(hyper.m) * ms * dt(-1))         # :888-889
+        tlo, thi = eps, dt(math.pi) - eps
+        theta_m = np.clip(raw, tlo, thi)
+        zc = np.cos(theta_m) - onehot * (dt(hyper.m) + dt(hyper.m) * ms)    # :890-895
+        z = zc * dt(hyper.s)
+        cos_s = c * dt(hyper.s)
+        pass_clamp = (c_raw >= lo) & (c_raw <= hi)
+        inside = (raw >= tlo) & (raw <= thi)
+        dzdc = dt(hyper.s) * np.where(inside, np.sin(theta_m) / np.sqrt(dt(1) - c * c), dt(0))
+        extra.update(batch_mean=state.batch_mean, batch_std=state.batch_std, row_param=ms[:, 0].copy())
+    elif kind in (ELASTIC_ARC, ELASTIC_COS):
+        lo, hi = dt(-1) + dt(1e-7), dt(1) - dt(1e-7)
+        c = np.clip(c_raw, lo, hi)                                 # :997 / :1108
+        mrow = np.asarray(row_margin, dtype=dtype).reshape(N, 1)
+        if kind == ELASTIC_COS:
+            zc = c - onehot * mrow                                 # :1013
+            dzdc = np.full_like(c, dt(hyper.s))
+        else:
+            ty = c[rows, labels][:, None]
+            raw = np.arccos(ty) + mrow                             # :1126-1127
+            theta_m = np.clip(raw, dt(0), dt(math.pi))             # :1128
+            zc = c.copy()
+            zc[rows, labels] = np.cos(theta_m)[:, 0]               # :1129-1132
+            inside = (raw >= dt(0)) & (raw <= dt(math.pi))
+            dtar = np.where(inside, np.sin(theta_m) / np.sqrt(dt(1) - ty * ty), dt(0))
+            dzdc = dt(hyper.s) * np.where(onehot > 0, np.broadcast_to(dtar, c.shape), dt(1))
+        z = zc * dt(hyper.s)
+        cos_s = c * dt(hyper.s)
+        pass_clamp = (c_raw >= lo) & (c_raw <= hi)
+        extra.update(row_param=mrow[:, 0].copy())
+    elif kind == MAG:
+        lo, hi = dt(-1) + dt(1e-7), dt(1) - dt(1e-7)
+        la, ua = dt(hyper.l_a), dt(hyper.u_a)
+        xn = np.clip(xnorm, la, ua)                                # :1246
+        loss_g = float((dt(1) / (ua ** 2) * xn + dt(1) / xn).mean(dtype=np.float64))   # :1235-1239
+        c = np.clip(c_raw, lo, hi)                                 # :1261
+        slope = dt((hyper.u_margin - hyper.l_margin) / (hyper.u_a - hyper.l_a))
+        am = slope * (xn - la) + dt(hyper.l_margin)                # :1229-1233
+        cos_m, sin_m = np.cos(am), np.sin(am)
+        ty = c[rows, labels][:, None]
+        sin_t = np.sqrt(dt(1.0) - ty * ty + dt(1e-9))              # :1270
+        ctm = ty * cos_m - sin_t * sin_m                           # :1271
+        d_c = cos_m + sin_m * ty / sin_t
+        d_m = -ty * sin_m - sin_t * cos_m
+        if hyper.easy_margin:
+            on = ty > 0                                            # :1274
+            off_z, off_dm = ty, np.zeros_like(ty)
+        else:
+            mm = np.sin(dt(math.pi) - am) * am                     # :1277
+            on = ty > np.cos(dt(math.pi) - am)                     # :1278-1279
+            off_z = ty - mm
+            off_dm = np.cos(dt(math.pi) - am) * am - np.sin(dt(math.pi) - am)
+        final_t = np.where(on, ctm, off_z)
+        zc = c.copy()
+        zc[rows, labels] = final_t[:, 0]                           # :1286
+        z = zc * dt(hyper.s)                                       # :1287
+        cos_s = c * dt(hyper.s)
+        pass_clamp = (c_raw >= lo) & (c_raw <= hi)
+        dtar = np.where(on, d_c, dt(1))
+        dzdc = dt(hyper.s) * np.where(onehot > 0, np.broadcast_to(dtar, c.shape), dt(1))
+        norm_pass = ((xnorm >= la) & (xnorm <= ua)).astype(dtype)
+        # d z_target / d||x|| through the adaptive margin, and d loss_g / d||x||
+        mag_dz_dnorm = dt(hyper.s) * np.where(on, d_m, off_dm) * slope * norm_pass
+        mag_dg_dnorm = (dt(1) / (ua ** 2) - dt(1) / (xn * xn)) * norm_pass / dt(N)
+        extra.update(loss_g=loss_g, row_param=am[:, 0].copy(), x_norm=xn.astype(dtype))
     else:
         raise ValueError(kind)
 
@@ -199,11 +329,15 @@ def head_forward_backward(kind, x, w, labels, hyper: HeadHyper, state: HeadState
         if dnorm_coef is not None:                                 # SphereFace: grad through ||x||
             dn = (g * dnorm_coef).sum(axis=1, keepdims=True)
             dx = dx + dn * xh
+        if kind == MAG:                                            # grad through ||x||: adaptive margin + loss_g
+            dn = g[rows, labels][:, None] * mag_dz_dnorm + dt(lambda_g) * mag_dg_dnorm
+            dx = dx + dn * xh
         dw = dwc if weight_is_cd(kind) else dwc.T
         dx = dx.astype(dtype)
         dw = np.ascontiguousarray(dw.astype(dtype))
 
-    return HeadOut(cos_s=cos_s.astype(dtype), logits=z.astype(dtype), norms=xnorm.astype(dtype),
+    return HeadOut(cos_s=cos_s.astype(dtype), logits=z.astype(dtype),
+                   norms=(extra["x_norm"] if kind == MAG else xnorm).astype(dtype),
                    loss=loss, top1=top1, top5=top5, dx=dx, dw=dw, lse=lse, extra=extra)
 
 

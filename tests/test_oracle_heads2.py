@@ -1,0 +1,95 @@
+"""Pin the oracle's restatement of the SURVEY 8(f)-3 heads (MV-Softmax am/arc, AdaFace, ElasticArcFace,
+ElasticCosFace, MagFace with and without easy_margin) to golden vectors captured from the reference import
+(tests/golden/make_golden_heads2.py): forward, CE, loss_g, analytic backward of CE + lambda_g * loss_g, state.  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import heads as H
+
+CASES = {"mv_am": H.MV_AM, "mv_arc": H.MV_ARC, "adaface": H.ADA, "elastic_arc": H.ELASTIC_ARC,
+         "elastic_cos": H.ELASTIC_COS, "magface": H.MAG, "magface_easy": H.MAG}
+
+
+def load_case(golden_dir, name, tag):
+    g = np.load(os.path.join(golden_dir, f"heads_{name}.npz"))
+    kind = CASES[name]
+    hyper = H.HeadHyper.default(kind)
+    if name == "magface_easy":
+        hyper.easy_margin = True
+    st = H.HeadState(batch_mean=float(g[f"{tag}_pre_batch_mean"]), batch_std=float(g[f"{tag}_pre_batch_std"]))
+    margins = g[f"{tag}_row_margin"] if f"{tag}_row_margin" in g.files else None
+    return g, kind, hyper, st, margins
+
+
+def ill_rows(g, tag, kind, s):
+    """Rows whose target cosine sits on a clamp limit: acos / sqrt(1 - c^2) there swing by 1e-3 per ulp of c in
+    the reference itself (the fixture plants two such rows on purpose); they get a loose bound."""
+    y = g[f"{tag}_y"]
+    ty = g[f"{tag}_cos_s"][np.arange(len(y)), y] / s
+    lim = 1e-3 if kind == H.ADA else 1e-5
+    return np.abs(ty) > 1 - 2 * lim
+
+
+@pytest.mark.parametrize("name", list(CASES))
+@pytest.mark.parametrize("tag", ["fresh", "warm"])
+def test_head_matches_reference(golden_dir, name, tag):
+    g, kind, hyper, st, margins = load_case(golden_dir, name, tag)
+    lam = float(g["lambda_g"])
+    out = H.head_forward_backward(kind, g[f"{tag}_x"], g[f"{tag}_w"], g[f"{tag}_y"], hyper, st, dtype=np.float32,
+                                  row_margin=margins, lambda_g=lam)
+    y = g[f"{tag}_y"]
+    ill = ill_rows(g, tag, kind, hyper.s)
+    ok = ~ill
+    np.testing.assert_allclose(out.cos_s, g[f"{tag}_cos_s"], atol=2e-4, rtol=0)
+    np.testing.assert_allclose(out.logits[ok], g[f"{tag}_logits"][ok], atol=3e-4, rtol=0)
+    np.testing.assert_allclose(out.logits[ill], g[f"{tag}_logits"][ill], atol=0.2, rtol=0)
+    np.testing.assert_allclose(out.norms, g[f"{tag}_norms"], rtol=1e-6)           # MagFace: the clamped x_norm
+    assert abs(out.loss - float(g[f"{tag}_loss"])) < (1e-4 if not ill.any() else 2e-2)
+    assert out.extra.get("loss_g", 0.0) == pytest.approx(float(g[f"{tag}_loss_g"]), rel=1e-5, abs=1e-9)
+    sx, sw = np.abs(g[f"{tag}_dx"]).max(), np.abs(g[f"{tag}_dw"]).max()
+    np.testing.assert_allclose(out.dx[ok], g[f"{tag}_dx"][ok], atol=3e-4 * sx, rtol=0)
+    wc = (lambda a: a) if H.weight_is_cd(kind) else (lambda a: a.T)
+    okc = np.ones(wc(out.dw).shape[0], dtype=bool)
+    okc[y[ill]] = False
+    np.testing.assert_allclose(wc(out.dw)[okc], wc(g[f"{tag}_dw"])[okc], atol=3e-4 * sw, rtol=0)
+    n = len(y)
+    assert 100.0 * out.top1 / n == pytest.approx(float(g[f"{tag}_acc1"]), abs=1e-4)
+    assert 100.0 * out.top5 / n == pytest.approx(float(g[f"{tag}_acc5"]), abs=1e-4)
+    if kind == H.ADA:
+        assert st.batch_mean == pytest.approx(float(g[f"{tag}_post_batch_mean"]), rel=1e-5)
+        assert st.batch_std == pytest.approx(float(g[f"{tag}_post_batch_std"]), rel=1e-5)
+    assert float(g[f"{tag}_onehot_sum"]) == n
+
+
+def test_fixture_exercises_the_branches(golden_dir):
+    """MV mask fires on non-targets; MagFace sees norms below l_a, inside, and above u_a, and both margin branches;
+    AdaFace's margin scaler takes both signs; the elastic margins are inside [m - std, m + std]."""
+    g = np.load(os.path.join(golden_dir, "heads_mv_arc.npz"))
+    y = g["fresh_y"]; rows = np.arange(len(y))
+    c = g["fresh_cos_s"] / 32.0
+    moved = ~np.isclose(g["fresh_logits"], g["fresh_cos_s"], atol=1e-6)
+    moved[rows, y] = False
+    assert moved.any()
+    g = np.load(os.path.join(golden_dir, "heads_magface.npz"))
+    nr = np.linalg.norm(g["fresh_x"], axis=1)
+    assert (nr < 10).any() and (nr > 110).any() and ((nr > 10) & (nr < 110)).any()
+    y = g["fresh_y"]; rows = np.arange(len(y))
+    ty = g["fresh_cos_s"][rows, y] / 64.0
+    am = (0.8 - 0.45) / 100.0 * (np.clip(nr, 10, 110) - 10) + 0.45
+    assert (ty > np.cos(np.pi - am)).any() and (ty <= np.cos(np.pi - am)).any()
+    g, kind, hyper, st, _ = load_case(golden_dir, "adaface", "warm")
+    out = H.head_forward_backward(kind, g["warm_x"], g["warm_w"], g["warm_y"], hyper, st, need_grad=False)
+    assert (out.extra["row_param"] > 0).any() and (out.extra["row_param"] < 0).any()
+    g = np.load(os.path.join(golden_dir, "heads_elastic_arc.npz"))
+    assert np.all(np.abs(g["fresh_row_margin"] - 0.5) <= 0.0125 + 1e-7) and g["fresh_row_margin"].std() > 0
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_float64_gradients_tight(golden_dir, name):
+    g, kind, hyper, st, margins = load_case(golden_dir, name, "warm")
+    out = H.head_forward_backward(kind, g["warm_x"], g["warm_w"], g["warm_y"], hyper, st, dtype=np.float64,
+                                  row_margin=margins, lambda_g=float(g["lambda_g"]))
+    ok = ~ill_rows(g, "warm", kind, hyper.s)
+    np.testing.assert_allclose(out.dx[ok], g["warm_dx"][ok], atol=3e-4 * np.abs(g["warm_dx"]).max(), rtol=0)
