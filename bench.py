@@ -120,7 +120,9 @@ def run():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
     ap.add_argument("--classes", type=int, default=10575)
-    ap.add_argument("--head", default="arcface")
+    ap.add_argument("--head", default="arcface",
+                    help="arcface | cosface | sphereface | curricular | mv_am | mv_arc | adaface | elastic_arc | elastic_cos | magface")
+    ap.add_argument("--lambda-g", type=float, default=0.0, help="MagFace: weight of loss_g (model_utils.py:180, 482)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--lr", type=float, default=0.005)
     ap.add_argument("--no-graph", action="store_true")
@@ -146,7 +148,7 @@ def run():
 
     from frx import ddp, engine as E, ops
     dt = ops.BF16 if args.dtype == "bf16" else ops.F32
-    eng = E.FaceEngine(args.head, args.classes, args.batch, dtype=dt, device=dev, seed=0)   # same init on all ranks
+    eng = E.FaceEngine(args.head, args.classes, args.batch, dtype=dt, device=dev, seed=0, lambda_g=args.lambda_g)   # same init on all ranks
     if world > 1:
         eng.world = world            # grad_scale 1/world in the fused SGD; the all-reduce is issued by the step below
     g = torch.Generator().manual_seed(1234 + rank)

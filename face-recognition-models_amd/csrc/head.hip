@@ -598,7 +598,7 @@ __global__ __launch_bounds__(256) void k_head_grad(HeadConst h, const float* __r
   if (KIND == FRX_SPHERE || KIND == FRX_MAG) {
     dnorm = block_sum256(dnorm, sh);
     if (threadIdx.x == 0) {
-      if (KIND == FRX_MAG && !dlogits && r.xnorm >= h.p2 && r.xnorm <= h.p3) {        // + lambda_g * d loss_g / d||x||  (criterion.py:1235-1239)
+      if (KIND == FRX_MAG && r.xnorm >= h.p2 && r.xnorm <= h.p3) {   // + lamb * d loss_g / d||x||  (criterion.py:1235-1239); gs = 1/N in dlogits mode
         const float xn = r.xnorm;                               // clamp inactive here, so x_norm == ||x||
         dnorm += h.lamb * gs * (1.f / (h.p3 * h.p3) - 1.f / (xn * xn));
       }

@@ -618,27 +618,44 @@ class ResNet50Engine:
         return missing
 
 
-HEAD_KINDS = {"arcface": ops.ARC, "cosface": ops.COS, "sphereface": ops.SPHERE, "curricular": ops.CURR}
-# (s, m) per head: main_code/utils/config.py:16-37.  SphereFace ignores s (criterion.py:119-123).
-HEAD_DEFAULTS = {ops.ARC: (64.0, 0.5), ops.COS: (64.0, 0.35), ops.SPHERE: (1.0, 2.0), ops.CURR: (64.0, 0.5)}
+HEAD_KINDS = {"arcface": ops.ARC, "cosface": ops.COS, "sphereface": ops.SPHERE, "curricular": ops.CURR,
+              "mv_am": ops.MV_AM, "mv_arc": ops.MV_ARC, "adaface": ops.ADA, "elastic_arc": ops.ELASTIC_ARC,
+              "elastic_cos": ops.ELASTIC_COS, "magface": ops.MAG}
+# (s, m) per head: main_code/utils/config.py:16-70.  SphereFace ignores s (criterion.py:119-123); the elastic heads
+# sample their margin around m; MagFace derives it from the feature norm.
+HEAD_DEFAULTS = {ops.ARC: (64.0, 0.5), ops.COS: (64.0, 0.35), ops.SPHERE: (1.0, 2.0), ops.CURR: (64.0, 0.5),
+                 ops.MV_AM: (32.0, 0.35), ops.MV_ARC: (32.0, 0.35), ops.ADA: (64.0, 0.4), ops.ELASTIC_ARC: (64.0, 0.5),
+                 ops.ELASTIC_COS: (64.0, 0.35), ops.MAG: (64.0, 0.0)}
+# frx_head_desc::p defaults: MV mv_weight (config.py:30); ADA h, t_alpha (:49-50); MAG l_margin, u_margin, l_a, u_a (:67-70)
+HEAD_P_DEFAULTS = {ops.MV_AM: (1.12,), ops.MV_ARC: (1.12,), ops.ADA: (0.333, 0.99), ops.MAG: (0.45, 0.8, 10.0, 110.0)}
+ELASTIC_KINDS = (ops.ELASTIC_ARC, ops.ELASTIC_COS)
 
 
 class FaceEngine:
     """Backbone + margin head + fused SGD: one training step = forward, CE, backward, update."""
 
     def __init__(self, kind, num_classes, batch, dtype=BF16, device="cuda:0", s=None, m=None, momentum=0.01, seed=None,
-                 share=None):
+                 share=None, head_p=None, head_flags=0, lambda_g=0.0, elastic_std=0.0125):
         self.kind = HEAD_KINDS[kind] if isinstance(kind, str) else kind
         self.C, self.N = num_classes, batch
         ds, dm = HEAD_DEFAULTS[self.kind]
         self.s, self.m = (ds if s is None else s), (dm if m is None else m)
-        self.w_cd = self.kind in (ops.ARC, ops.SPHERE)
+        self.w_cd = self.kind in ops.W_CD_KINDS
         self.net = ResNet50Engine(batch, dtype, device, extra_params=num_classes * FEATURE_DIM,
                                   share=None if share is None else share.net)
         self.device = self.net.device
-        self.head = ops.HeadContext(self.kind, batch, FEATURE_DIM, num_classes, self.s, self.m, momentum, device=self.device)
-        # CurricularFace buffer `t` (criterion.py:517)
-        self.t = torch.zeros(1, device=self.device) if share is None else share.t
+        self.head_p = tuple(HEAD_P_DEFAULTS.get(self.kind, ()) if head_p is None else head_p)
+        self.elastic_std = float(elastic_std)
+        self.head = ops.HeadContext(self.kind, batch, FEATURE_DIM, num_classes, self.s, self.m, momentum, device=self.device,
+                                    p=self.head_p, flags=head_flags, lambda_g=lambda_g)
+        # Head state (include/frx.h, `state_t`): CurricularFace's `t` [1] (criterion.py:517); AdaFace's batch_mean /
+        # batch_std [2] (:838-839), shared between batch sizes like `t`; the elastic heads' per-row margins [N].
+        if self.kind in ELASTIC_KINDS:
+            self.t = torch.full((batch,), float(self.m), device=self.device)
+        elif self.kind == ops.ADA:
+            self.t = torch.tensor([20.0, 100.0], device=self.device) if share is None else share.t
+        else:
+            self.t = torch.zeros(1, device=self.device) if share is None else share.t
         self.sphere_iter = 0                                 # SphereFace.iter (criterion.py:33): python int
         self.dfeat = torch.zeros(batch, FEATURE_DIM, device=self.device)
         self.last = None
@@ -647,6 +664,17 @@ class FaceEngine:
         self.ty_allreduce = None
         if share is None:
             self.reset_head(seed)
+
+    def set_lambda_g(self, lambda_g):
+        """MagFace: weight of loss_g in the total loss the fused backward differentiates (model_utils.py:180)"""
+        if self.kind == ops.MAG:
+            self.head.desc.lamb = float(lambda_g)
+
+    def sample_margins(self):
+        """Elastic heads: this step's per-row margins, normal(m, std) clamped to [m - std, m + std]
+        (criterion.py:1002-1004, 1113-1115).  In place on the static buffer (graph replays read it)."""
+        if self.kind in ELASTIC_KINDS:
+            self.t.normal_(float(self.m), self.elastic_std).clamp_(self.m - self.elastic_std, self.m + self.elastic_std)
 
     # head weight views, in the reference's own layouts (SURVEY H7)
     def head_w(self, buf=None):
@@ -661,12 +689,19 @@ class FaceEngine:
         if self.kind in (ops.ARC, ops.SPHERE):      # xavier_uniform_ on [C,D] (criterion.py:244,37)
             bound = math.sqrt(6.0 / (C + D))
             w = (torch.rand(C, D, generator=g) * 2 - 1) * bound
-        elif self.kind == ops.COS:                   # uniform(-1,1).renorm_(2,1,1e-5).mul_(1e5) (criterion.py:152)
+        elif self.kind in (ops.MV_AM, ops.MV_ARC):   # same expression on [C,D] (criterion.py:367)
+            w = (torch.rand(C, D, generator=g) * 2 - 1).renorm_(2, 1, 1e-5).mul_(1e5)
+        elif self.kind in (ops.COS, ops.ADA, ops.MAG):   # uniform(-1,1).renorm_(2,1,1e-5).mul_(1e5) (criterion.py:152,833,1216)
             w = (torch.rand(D, C, generator=g) * 2 - 1).renorm_(2, 1, 1e-5).mul_(1e5)
-        else:                                        # normal(std=0.01) (criterion.py:514)
+        else:                                        # normal(std=0.01) (criterion.py:514,973,1080)
             w = torch.randn(D, C, generator=g) * 0.01
         self.head_w().copy_(w)
-        self.t.zero_()
+        if self.kind == ops.ADA:
+            self.t.copy_(torch.tensor([20.0, 100.0]))
+        elif self.kind in ELASTIC_KINDS:
+            self.t.fill_(float(self.m))
+        else:
+            self.t.zero_()
         self.sphere_iter = 0
 
     def _lamb(self):
@@ -674,7 +709,11 @@ class FaceEngine:
         self.sphere_iter += 1
         return max(5.0, 1000.0 * (1 + 0.12 * self.sphere_iter) ** (-1))
 
-    def forward_loss(self, images, labels, want_logits=False):
+    def forward_loss(self, images, labels, want_logits=False, sample=True):
+        """sample=False: keep the elastic margins already in the state buffer (a captured graph replays this
+        function's kernels only; call sample_margins() before each replay)"""
+        if sample:
+            self.sample_margins()
         feats = self.net.forward(images)
         lamb = self._lamb() if self.kind == ops.SPHERE else 0.0
         self.last = ops.head_forward(self.head, feats, self.head_w(), labels, state_t=self.t, lamb=lamb,

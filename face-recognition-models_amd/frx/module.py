@@ -88,7 +88,7 @@ class NativeFaceNet(nn.Module):
     # ------------------------------------------------------------------ engine management
     @property
     def head(self):
-        return getattr(self, self.head_attr)
+        return self._modules[self.head_attr]      # (the elastic *Nets name the attribute itself `head`)
 
     def _head_param(self):
         return self.head.weight if hasattr(self.head, "weight") else self.head.kernel
@@ -104,7 +104,9 @@ class NativeFaceNet(nn.Module):
             return eng
         h = self.head
         eng = E.FaceEngine(self.kind, h.num_classes, n, dtype=self._dtype, device=device, s=h.s, m=float(h.m),
-                           momentum=getattr(h, "momentum", 0.01), share=self._primary)
+                           momentum=getattr(h, "momentum", 0.01), share=self._primary,
+                           head_p=getattr(h, "frx_p", None), head_flags=getattr(h, "frx_flags", 0),
+                           elastic_std=getattr(h, "std", 0.0125))
         if self._primary is None:
             self._adopt(eng)
         self._engines[n] = eng
@@ -116,8 +118,10 @@ class NativeFaceNet(nn.Module):
         sd = {k: v.detach() for k, v in self.backbone.state_dict().items()}
         net.load_state_dict(sd)
         eng.head_w().copy_(self._head_param().detach().to(eng.device))
-        if hasattr(self.head, "t"):
+        if eng.kind == ops.CURR:
             eng.t.copy_(self.head.t.detach().to(eng.device))
+        elif eng.kind == ops.ADA:
+            eng.t.copy_(torch.cat([self.head.batch_mean.detach().view(1), self.head.batch_std.detach().view(1)]).to(eng.device))
         mods = dict(self.backbone.named_modules())
 
         def sub(dotted):
@@ -140,8 +144,11 @@ class NativeFaceNet(nn.Module):
         self._alias(self.backbone.fc, "bias", net.fc_b(), net.fc_b(net.grads))
         pname = "weight" if hasattr(self.head, "weight") else "kernel"
         self._alias(self.head, pname, eng.head_w(), eng.head_w(net.grads))
-        if hasattr(self.head, "t"):
+        if eng.kind == ops.CURR:
             self.head.t = eng.t
+        elif eng.kind == ops.ADA:                      # the two EMA buffers live in the engine's head state
+            self.head.batch_mean, self.head.batch_std = eng.t[0:1], eng.t[1:2]
+            self.head.t = self.head.t.to(eng.device)
         self._primary = eng
         self._param_list = list(self.parameters())
         self._synced_version = self._version_sum()
@@ -224,24 +231,32 @@ class _TrainForward(torch.autograd.Function):
                 h.iter += 1
                 h.lamb = max(h.LambdaMin, h.base * (1 + h.gamma * h.iter) ** (-h.power))
                 lamb = h.lamb
+            eng.sample_margins()                       # elastic heads: this step's margins (criterion.py:1002,1113)
             feats = eng.net.forward(x.contiguous())
             out = ops.head_forward(eng.head, feats, eng.head_w(), labels, state_t=eng.t, lamb=lamb, want_logits=True,
                                    ty_allreduce=eng.ty_allreduce)
         anchor = model._head_param()
-        logits = _TrainForward.apply(anchor, out["logits"], model, eng, labels)
+        is_mag = eng.kind == ops.MAG
+        logits, loss_g = _TrainForward.apply(anchor, out["logits"], out["loss_g"][0] if is_mag else None, model, eng, labels)
         one_hot = torch.zeros_like(out["cos_s"]).scatter_(1, labels.view(-1, 1), 1.0)
         model._last_ctx = out
-        return [out["cos_s"], logits], out["norms"].view(-1, 1), 0, one_hot
+        # MagFace returns the clamped x_norm and a differentiable loss_g (criterion.py:1291); the others norms and 0
+        return [out["cos_s"], logits], out["norms"].view(-1, 1), (loss_g if is_mag else 0), one_hot
 
     @staticmethod
-    def forward(ctx, anchor, logits, model, eng, labels):
+    def forward(ctx, anchor, logits, loss_g, model, eng, labels):
         ctx.model, ctx.eng, ctx.labels = model, eng, labels
-        return logits.view_as(logits)
+        ctx.set_materialize_grads(False)
+        return logits.view_as(logits), (None if loss_g is None else loss_g.view_as(loss_g))
 
     @staticmethod
-    def backward(ctx, dlogits):
+    def backward(ctx, dlogits, dloss_g):
         model, eng, labels = ctx.model, ctx.eng, ctx.labels
         params = model._begin_backward()
+        if dlogits is None:
+            dlogits = torch.zeros(eng.N, eng.C, device=eng.device)
+        if eng.kind == ops.MAG:                         # upstream dL/dloss_g (= args.lambda_g, model_utils.py:180)
+            eng.head.desc.lamb = 0.0 if dloss_g is None else float(dloss_g)
         ops.head_backward_dlogits(eng.head, eng.net.feats, eng.head_w(), labels, dlogits.contiguous().float(),
                                   state_t=eng.t, dx=eng.dfeat, dw=eng.head_w(eng.net.grads), accumulate_dw=True)
         eng.net.backward(eng.dfeat)
@@ -249,4 +264,4 @@ class _TrainForward(torch.autograd.Function):
             eng.allreduce(eng.net.grads)
             eng.net.grads.mul_(1.0 / eng.world)
         model._publish_grads(params)
-        return None, None, None, None, None
+        return None, None, None, None, None, None

@@ -180,19 +180,22 @@ def train_model(model, train_loader, criterion, optimizer, scaler, device, epoch
     progress = ProgressMeter(len(train_loader), [meters["bt"], meters["dt"], meters["tp"], "images/s", meters["loss"],
                                                  meters["lid"], meters["lmag"], meters["a1"], meters["a5"]],
                              prefix=f"Epoch: [{epoch}/{epochs}]")
-    fused = isinstance(model, NativeFaceNet) and isinstance(optimizer, FusedSGD) and _is_plain_ce(criterion) \
-        and getattr(args, "lambda_g", 0.0) == 0.0
+    # (loss_g is the integer 0 for every head but MagFace, whose fused backward takes lambda_g itself)
+    fused = isinstance(model, NativeFaceNet) and isinstance(optimizer, FusedSGD) and _is_plain_ce(criterion)
+    lambda_g = float(getattr(args, "lambda_g", 0.0))
     _ITERS["n"] += 1
     pending = []                 # (device loss, device top-k counts, batch size) not yet synced to the host
     end = time.time()
 
     def flush():
-        for loss_t, topk_t, n, lr in pending:
-            lv = float(loss_t)
+        for loss_t, topk_t, n, lr, lg_t in pending:
+            lid = float(loss_t)
+            mag = lambda_g * (float(lg_t) if lg_t is not None else 0.0)
+            lv = lid + mag
             a1, a5 = (float(v) * 100.0 / n for v in topk_t.tolist())
-            meters["loss"].update(lv, n); meters["lid"].update(lv, n); meters["lmag"].update(0.0, n)
+            meters["loss"].update(lv, n); meters["lid"].update(lid, n); meters["lmag"].update(mag, n)
             meters["a1"].update(a1, n); meters["a5"].update(a5, n)
-            wandb.log({"loss": lv, "loss_id": lv, "loss_mag": 0.0, "acc1": a1, "acc5": a5, "lr": lr, "epoch": epoch,
+            wandb.log({"loss": lv, "loss_id": lid, "loss_mag": mag, "acc1": a1, "acc5": a5, "lr": lr, "epoch": epoch,
                        "step": _ITERS["n"]}, step=_ITERS["n"])
             _ITERS["n"] += 1
         pending.clear()
@@ -213,11 +216,13 @@ def train_model(model, train_loader, criterion, optimizer, scaler, device, epoch
             optimizer._apply_pending(eng)
             if eng.kind == ops.SPHERE:
                 eng.sphere_iter = model.head.iter
+            eng.set_lambda_g(lambda_g)
             out = eng.train_step(images.contiguous(), target.contiguous(), lr)
             if eng.kind == ops.SPHERE:
                 model.head.iter = eng.sphere_iter
             model._synced_version = model._version_sum()
-            pending.append((out["loss"].clone(), out["topk"].clone(), n, lr))
+            pending.append((out["loss"].clone(), out["topk"].clone(), n, lr,
+                            out["loss_g"].clone() if eng.kind == ops.MAG else None))
         else:
             output, norm, loss_g, one_hot = model(images, target)
             cosine_s, logits = output

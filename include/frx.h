@@ -67,8 +67,8 @@ typedef struct frx_head_desc {
   float s, m;        /* scale / margin (config.py:16-70); SPHERE ignores s, m must be 2; ELASTIC / MAG ignore m */
   float momentum;    /* CURR EMA momentum (config.py:37) */
   float lamb;        /* SPHERE: annealing lambda for THIS forward (criterion.py:58-60; host state)
-                        MAG:    lambda_g, the weight of loss_g in the total loss (model_utils.py:180) -- used by
-                                frx_head_bwd only (frx_head_bwd_dlogits leaves loss_g to the caller's autograd) */
+                        MAG:    frx_head_bwd: lambda_g, the weight of loss_g in the total loss (model_utils.py:180);
+                                frx_head_bwd_dlogits: the upstream gradient dL/dloss_g (0 leaves loss_g out) */
   float p[4];        /* MV_*: p[0] = mv_weight (criterion.py:341)
                         ADA:  p[0] = h, p[1] = t_alpha (criterion.py:805-807)
                         MAG:  p[0] = l_margin, p[1] = u_margin, p[2] = l_a, p[3] = u_a (criterion.py:1188-1191) */

@@ -90,9 +90,11 @@ class ResNet50(nn.Module):
 
 
 class TorchHead(nn.Module):
-    """Autograd restatement of the four heads, used only to drive a whole-step oracle
+    """Autograd restatement of the heads, used only to drive a whole-step oracle
     (the closed-form numpy version in oracle/heads.py is the pinned one; this class is
-    checked against it in tests/test_oracle_heads.py)."""
+    checked against it in tests/test_oracle_heads.py).  After a forward, `loss_g` holds MagFace's
+    magnitude loss (0 for the other kinds) and `row_margin` the elastic heads' margins; setting
+    `next_margin` [N] before a forward replaces the torch.normal draw (criterion.py:1002, 1113)."""
 
     def __init__(self, kind, feat_dim, num_classes, hyper):
         super().__init__()
@@ -101,12 +103,13 @@ class TorchHead(nn.Module):
         self.state = H.HeadState()
         shape = (num_classes, feat_dim) if H.weight_is_cd(kind) else (feat_dim, num_classes)
         self.weight = nn.Parameter(torch.empty(shape))
+        self.loss_g, self.row_margin, self.next_margin, self.elastic_std = 0, None, None, 0.0125
         if kind in (H.ARC, H.SPHERE):
             nn.init.xavier_uniform_(self.weight)                       # criterion.py:244,37
-        elif kind == H.COS:
-            self.weight.data.uniform_(-1, 1).renorm_(2, 1, 1e-5).mul_(1e5)  # :152
+        elif kind in (H.COS, H.MV_AM, H.MV_ARC, H.ADA, H.MAG):
+            self.weight.data.uniform_(-1, 1).renorm_(2, 1, 1e-5).mul_(1e5)  # :152,367,833,1216
         else:
-            nn.init.normal_(self.weight, std=0.01)                     # :514
+            nn.init.normal_(self.weight, std=0.01)                     # :514,973,1080
 
     def forward(self, x, labels):
         import math
@@ -134,6 +137,49 @@ class TorchHead(nn.Module):
             phi = ((-1.0) ** k) * (2 * c * c - 1) - 2 * k
             nrm = torch.norm(x, p=2, dim=1, keepdim=True)
             return c * nrm, (onehot * (phi - c) / (1 + st.lamb) + c) * nrm
+        if self.kind in (H.MV_AM, H.MV_ARC):                           # criterion.py:414-441
+            c = c.clamp(-1 + 1e-7, 1 - 1e-7)
+            ty = c[rows, labels].view(-1, 1)
+            if self.kind == H.MV_AM:
+                fin, thr = torch.where(ty > hy.m, ty - hy.m, ty), ty - hy.m
+            else:
+                thr = ty * math.cos(hy.m) - torch.sqrt(1.0 - ty ** 2 + 1e-9) * math.sin(hy.m)
+                fin = torch.where(ty > 0.0, thr, ty)
+            z = torch.where(c > thr, hy.mv_weight * c + (hy.mv_weight - 1.0), c)
+            return c * hy.s, z.scatter(1, labels.view(-1, 1), fin) * hy.s
+        if self.kind == H.ADA:                                         # criterion.py:866-899
+            st, eps = self.state, 1e-3
+            c = c.clamp(-1 + eps, 1 - eps)
+            with torch.no_grad():
+                safe = torch.norm(x, p=2, dim=1, keepdim=True).clamp(0.001, 100)
+                st.batch_mean = float(safe.mean() * hy.t_alpha + (1 - hy.t_alpha) * st.batch_mean)
+                st.batch_std = float(safe.std() * hy.t_alpha + (1 - hy.t_alpha) * st.batch_std)
+                ms = ((safe - st.batch_mean) / (st.batch_std + eps) * hy.h).clamp(-1, 1)
+            theta_m = (c.acos() + onehot * (hy.m * ms * -1)).clamp(eps, math.pi - eps)
+            return c * hy.s, (theta_m.cos() - onehot * (hy.m + hy.m * ms)) * hy.s
+        if self.kind in (H.ELASTIC_ARC, H.ELASTIC_COS):                # criterion.py:997-1015, 1108-1135
+            c = c.clamp(-1 + 1e-7, 1 - 1e-7)
+            if self.next_margin is not None:
+                margin, self.next_margin = self.next_margin.view(-1, 1).to(c.dtype), None
+            else:
+                margin = torch.normal(mean=hy.m, std=self.elastic_std, size=(x.shape[0], 1))
+                margin = margin.clamp(hy.m - self.elastic_std, hy.m + self.elastic_std)
+            self.row_margin = margin.view(-1)
+            if self.kind == H.ELASTIC_COS:
+                return c * hy.s, (c - onehot * margin) * hy.s
+            fin = (c[rows, labels].acos().view(-1, 1) + margin).clamp(0, math.pi).cos()
+            return c * hy.s, c.scatter(1, labels.view(-1, 1), fin) * hy.s
+        if self.kind == H.MAG:                                         # criterion.py:1245-1289
+            xn = torch.norm(x, p=2, dim=1, keepdim=True).clamp(hy.l_a, hy.u_a)
+            self.loss_g = torch.mean(1 / (hy.u_a ** 2) * xn + 1 / xn)
+            c = c.clamp(-1 + 1e-7, 1 - 1e-7)
+            am = (hy.u_margin - hy.l_margin) / (hy.u_a - hy.l_a) * (xn - hy.l_a) + hy.l_margin
+            ctm = c * torch.cos(am) - torch.sqrt(1.0 - c ** 2 + 1e-9) * torch.sin(am)
+            if hy.easy_margin:
+                ctm = torch.where(c > 0, ctm, c)
+            else:
+                ctm = torch.where(c > torch.cos(math.pi - am), ctm, c - torch.sin(math.pi - am) * am)
+            return c * hy.s, (onehot * ctm + (1.0 - onehot) * c) * hy.s
         c = c.clamp(-1, 1)
         ty = c[rows, labels].view(-1, 1)
         cm = ty * math.cos(hy.m) - torch.sqrt(1.0 - ty * ty) * math.sin(hy.m)

@@ -93,3 +93,30 @@ def test_float64_gradients_tight(golden_dir, name):
                                   row_margin=margins, lambda_g=float(g["lambda_g"]))
     ok = ~ill_rows(g, "warm", kind, hyper.s)
     np.testing.assert_allclose(out.dx[ok], g["warm_dx"][ok], atol=3e-4 * np.abs(g["warm_dx"]).max(), rtol=0)
+
+
+def test_torch_head_matches_closed_form():
+    """oracle/resnet50.TorchHead (autograd, drives the whole-step oracle) == oracle/heads closed form for the new kinds,
+    including MagFace's loss_g term and the elastic heads' injected margins."""
+    import torch
+    import torch.nn.functional as F
+    from oracle.resnet50 import TorchHead
+    rng = np.random.RandomState(0)
+    for kind in (H.MV_AM, H.MV_ARC, H.ADA, H.ELASTIC_ARC, H.ELASTIC_COS, H.MAG):
+        torch.manual_seed(kind)
+        hy = H.HeadHyper.default(kind)
+        th = TorchHead(kind, 64, 40, hy)
+        x = rng.randn(16, 64).astype(np.float32)
+        x[::3] *= 3
+        x = torch.from_numpy(x).requires_grad_(True)
+        y = torch.from_numpy(rng.randint(0, 40, 16))
+        cos_s, logits = th(x, y)
+        loss_id = F.cross_entropy(logits, y)
+        (loss_id + 7.0 * th.loss_g).backward()
+        out = H.head_forward_backward(kind, x.detach().numpy(), th.weight.detach().numpy(), y.numpy(), hy, H.HeadState(),
+                                      dtype=np.float32, lambda_g=7.0,
+                                      row_margin=None if th.row_margin is None else th.row_margin.numpy())
+        assert abs(out.loss - loss_id.item()) < 1e-4
+        np.testing.assert_allclose(out.logits, logits.detach().numpy(), atol=2e-4)
+        np.testing.assert_allclose(out.dx, x.grad.numpy(), atol=2e-4 * np.abs(out.dx).max())
+        np.testing.assert_allclose(out.dw, th.weight.grad.numpy(), atol=2e-4 * np.abs(out.dw).max())
