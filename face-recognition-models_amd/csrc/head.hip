@@ -215,14 +215,14 @@ struct RowCtx {   // per-row values
 
 constexpr float kPi = 3.14159265358979323846f;
 constexpr bool kind_is_mv(int k) { return k == FRX_MV_AM || k == FRX_MV_ARC; }
-constexpr bool kind_eps7(int k) { return kind_is_mv(k) || k == FRX_ELASTIC_ARC || k == FRX_ELASTIC_COS || k == FRX_MAG; }
+constexpr bool kind_eps7(int k) { return kind_is_mv(k) || k == FRX_ELASTIC_ARC || k == FRX_ELASTIC_COS || k == FRX_MAG || k == FRX_VPL; }
 
 template <int KIND>
 __device__ __forceinline__ float head_clamp(float c) {
   if (KIND == FRX_ARC) return c;
   if (KIND == FRX_COS) return fminf(fmaxf(c, -1.f + 1e-4f), 1.f - 1e-4f);
   if (KIND == FRX_ADA) return fminf(fmaxf(c, -1.f + 1e-3f), 1.f - 1e-3f);          // criterion.py:866
-  if (kind_eps7(KIND)) return fminf(fmaxf(c, -1.f + 1e-7f), 1.f - 1e-7f);          // :414, :997, :1108, :1261
+  if (kind_eps7(KIND)) return fminf(fmaxf(c, -1.f + 1e-7f), 1.f - 1e-7f);          // :414, :724, :997, :1108, :1261
   return fminf(fmaxf(c, -1.f), 1.f);
 }
 template <int KIND>
@@ -318,6 +318,21 @@ __device__ __forceinline__ void head_z(float cc, bool target, const HeadConst& h
   } else if (KIND == FRX_ELASTIC_COS) {   // criterion.py:1013-1014
     z = (target ? cc - r.p : cc) * h.s;
     dzdc = h.s;
+  } else if (KIND == FRX_VPL) {           // criterion.py:727-739, on the blended cosine (frx_head_vpl_prepare)
+    if (target) {
+      const float sine = sqrtf(1.f - cc * cc + 1e-9f);
+      const bool on = (h.flags & 1) ? cc > 0.f : cc > h.th;
+      if (on) {
+        z = (cc * h.cos_m - sine * h.sin_m) * h.s;
+        dzdc = h.s * (h.cos_m + h.sin_m * cc / sine);
+      } else {
+        z = ((h.flags & 1) ? cc : cc - h.mm) * h.s;
+        dzdc = h.s;
+      }
+    } else {
+      z = cc * h.s;
+      dzdc = h.s;
+    }
   } else if (KIND == FRX_MAG) {           // criterion.py:1264-1284; u = dz/d(margin) feeds the norm gradient
     if (target) {
       const float cm_ = cosf(r.p), sm_ = sinf(r.p);
@@ -449,6 +464,68 @@ __global__ __launch_bounds__(256) void k_head_rowparam(HeadConst h, const float*
     }
     const float tot = block_sum256(part, sh);
     if (threadIdx.x == 0) *lossg = tot / (float)N;
+  }
+}
+
+// ---- VPL-ArcFace memory (criterion.py:699-722) ----
+// mem[cls] = mean of the RAW features of the batch rows labelled cls, life[cls] = delta.  One block per batch row;
+// the first row of each label does the work.
+__global__ __launch_bounds__(256) void k_vpl_mem_update(const float* __restrict__ x, const int64_t* __restrict__ labels,
+                                                        int N, int D, float delta, float* __restrict__ mem,
+                                                        float* __restrict__ life) {
+  __shared__ int first, cnt;
+  const int n = blockIdx.x;
+  const int64_t y = labels[n];
+  if (threadIdx.x == 0) { first = N; cnt = 0; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < N; i += 256)
+    if (labels[i] == y) { atomicMin(&first, i); atomicAdd(&cnt, 1); }
+  __syncthreads();
+  if (first != n) return;
+  for (int dd = threadIdx.x; dd < D; dd += 256) {
+    float acc = 0.f;
+    for (int i = n; i < N; ++i)
+      if (labels[i] == y) acc += x[(long)i * D + dd];
+    mem[(long)y * D + dd] = acc / (float)cnt;
+  }
+  if (threadIdx.x == 0) life[y] = delta;
+}
+
+__global__ __launch_bounds__(256) void k_vpl_life_decay(float* __restrict__ life, int C) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j < C) life[j] -= 1.f;
+}
+
+// c = (1 - a*lamda) * cos_w + a*lamda * (target ? 1 : cos_mem),  a = life > 0   (in place over cos_w)
+__global__ __launch_bounds__(256) void k_vpl_blend(float* __restrict__ cbuf, const float* __restrict__ cmem,
+                                                   const float* __restrict__ life, const int64_t* __restrict__ labels,
+                                                   int C, long ldc, float lamda) {
+  const int n = blockIdx.x;
+  const int y = (int)labels[n];
+  for (int j = threadIdx.x; j < C; j += 256) {
+    const float al = (life[j] > 0.f ? 1.f : 0.f) * lamda;
+    const long i = (long)n * ldc + j;
+    cbuf[i] = (1.f - al) * cbuf[i] + al * (j == y ? 1.f : cmem[i]);
+  }
+}
+
+// backward of the blend: g -> (g * (1 - a*lamda) for the weight path, g * a*lamda (non-target) for the memory path)
+__global__ __launch_bounds__(256) void k_vpl_split(float* __restrict__ gbuf, float* __restrict__ gmem,
+                                                   const float* __restrict__ life, const int64_t* __restrict__ labels,
+                                                   int C, int Cpad, float lamda) {
+  const int n = blockIdx.x;
+  const int y = (int)labels[n];
+  for (int j = threadIdx.x; j < Cpad; j += 256) {
+    const long i = (long)n * Cpad + j;
+    float gw = 0.f, gm = 0.f;
+    if (j < C) {
+      const float al = (life[j] > 0.f ? 1.f : 0.f) * lamda;
+      const float g = gbuf[i];
+      gw = g * (1.f - al);
+      gm = j == y ? 0.f : g * al;
+    }
+    gbuf[i] = gw;
+    gmem[i] = gm;
   }
 }
 
@@ -706,6 +783,7 @@ __global__ __launch_bounds__(256) void k_copy_f32(const float* __restrict__ x, f
 // ------------------------------------------------------------------------------------------
 struct HeadWs {
   float *xinv, *xnorm, *winv, *ty, *tysum, *rowloss, *lse, *dn, *rowp, *xn, *lossg, *cbuf, *gbuf, *dxh, *dwh;
+  float *minv, *cbuf2, *gbuf2;     // VPL: inverse norms of the memory rows, cosine against the memory, its gradient
   int32_t* rowrank;
   int Cpad, Npad;
   size_t bytes;
@@ -730,13 +808,19 @@ static HeadWs carve(const frx_head_desc* d, void* base) {
   w.gbuf = take((size_t)d->N * w.Cpad);
   w.dxh = take((size_t)d->N * d->D);
   w.dwh = take((size_t)d->C * d->D);
+  w.minv = w.cbuf2 = w.gbuf2 = nullptr;
+  if (d->kind == FRX_VPL) {
+    w.minv = take(w.Cpad);
+    w.cbuf2 = take((size_t)d->N * w.Cpad);
+    w.gbuf2 = take((size_t)d->N * w.Cpad);
+  }
   w.bytes = off;
   return w;
 }
 
 static int check_desc(const frx_head_desc* d) {
   FRX_CHECK_ARG(d != nullptr, "head desc is NULL");
-  FRX_CHECK_ARG(d->kind >= FRX_ARC && d->kind <= FRX_MAG, "unknown head kind %d", d->kind);
+  FRX_CHECK_ARG(d->kind >= FRX_ARC && d->kind <= FRX_VPL, "unknown head kind %d", d->kind);
   FRX_CHECK_ARG(d->N > 0 && d->C > 0 && d->D > 0, "head dims must be positive (N=%d D=%d C=%d)", d->N, d->D, d->C);
   FRX_CHECK_ARG(d->D % 16 == 0, "head feature dim D=%d must be a multiple of 16", d->D);
   FRX_CHECK_ARG(d->kind != FRX_SPHERE || d->m == 2.f, "SphereFace supports m=2 only (config.py:17), got %g", (double)d->m);
@@ -761,13 +845,15 @@ static HeadConst make_const(const frx_head_desc* d) {
   return h;
 }
 
-static bool w_is_cd(int kind) { return kind == FRX_ARC || kind == FRX_SPHERE || kind == FRX_MV_AM || kind == FRX_MV_ARC; }
+static bool w_is_cd(int kind) { return kind == FRX_ARC || kind == FRX_SPHERE || kind == FRX_MV_AM || kind == FRX_MV_ARC || kind == FRX_VPL; }
+static bool vpl_memory_on(const frx_head_desc* d) { return d->kind == FRX_VPL && (d->flags & 2); }
 static bool needs_state(int kind) {
-  return kind == FRX_CURR || kind == FRX_ADA || kind == FRX_ELASTIC_ARC || kind == FRX_ELASTIC_COS;
+  return kind == FRX_CURR || kind == FRX_ADA || kind == FRX_ELASTIC_ARC || kind == FRX_ELASTIC_COS || kind == FRX_VPL;
 }
 static const char* state_what(int kind) {
   return kind == FRX_CURR ? "CurricularFace needs the `t` buffer"
        : kind == FRX_ADA  ? "AdaFace needs its [batch_mean, batch_std] state"
+       : kind == FRX_VPL  ? "VPL-ArcFace needs its [mem | life] state"
                           : "the elastic heads need this step's per-row margins";
 }
 // expands M(KIND) for the runtime kind
@@ -782,6 +868,7 @@ static const char* state_what(int kind) {
     case FRX_ADA: M(FRX_ADA); break;                      \
     case FRX_ELASTIC_ARC: M(FRX_ELASTIC_ARC); break;      \
     case FRX_ELASTIC_COS: M(FRX_ELASTIC_COS); break;      \
+    case FRX_VPL: M(FRX_VPL); break;                      \
     default: M(FRX_MAG); break;                           \
   }
 
@@ -820,6 +907,34 @@ extern "C" int frx_head_fwd_cos(int device, frx_stream_t stream, const frx_head_
 #define FRX_TY(K) hipLaunchKernelGGL(k_head_ty<K>, dim3(1), dim3(256), 0, st, W.cbuf, d->N, (long)W.Cpad, labels, W.ty, tys)
   FRX_KIND_SWITCH(d->kind, FRX_TY)
 #undef FRX_TY
+  FRX_LAUNCH_CHECK();
+  return FRX_OK;
+}
+
+extern "C" int frx_head_vpl_prepare(int device, frx_stream_t stream, const frx_head_desc* d, const float* x,
+                                    const int64_t* labels, float* state_t, void* ws, size_t ws_bytes) {
+  if (int rc = check_desc(d)) return rc;
+  FRX_CHECK_ARG(d->kind == FRX_VPL, "head_vpl_prepare: kind %d is not FRX_VPL", d->kind);
+  if (!vpl_memory_on(d)) return FRX_OK;
+  FRX_CHECK_ARG(x && labels && state_t && ws, "head_vpl_prepare: NULL pointer");
+  FRX_ENTER(device);
+  hipStream_t st = (hipStream_t)stream;
+  HeadWs W = carve(d, ws);
+  if (ws_bytes < W.bytes) { set_error("head workspace too small: %zu < %zu", ws_bytes, W.bytes); return FRX_ERR_WORKSPACE; }
+  float* mem = state_t;
+  float* life = state_t + (size_t)d->C * d->D;
+  hipLaunchKernelGGL(k_vpl_mem_update, dim3(d->N), dim3(256), 0, st, x, labels, d->N, d->D, d->p[1], mem, life);
+  hipLaunchKernelGGL(k_vpl_life_decay, dim3(cdiv(d->C, 256)), dim3(256), 0, st, life, d->C);
+  hipLaunchKernelGGL(k_row_norms, dim3(cdiv(d->C, 4)), dim3(256), 0, st, (const float*)mem, d->C, d->D, W.minv, (float*)nullptr);
+  FRX_LAUNCH_CHECK();
+  GemmArgs g{};
+  g.A = x; g.lda = d->D; g.a_mcontig = 0;
+  g.B = mem; g.M = d->N; g.N = d->C; g.K = d->D; g.b_ncontig = 0; g.ldb = d->D;
+  g.C = W.cbuf2; g.ldc = W.Cpad; g.row_scale = W.xinv; g.col_scale = W.minv;
+  if (int rc = launch_gemm(st, g, 1)) return rc;
+  hipLaunchKernelGGL(k_vpl_blend, dim3(d->N), dim3(256), 0, st, W.cbuf, (const float*)W.cbuf2, (const float*)life, labels,
+                     d->C, (long)W.Cpad, d->p[0]);
+  hipLaunchKernelGGL(k_head_ty<FRX_VPL>, dim3(1), dim3(256), 0, st, W.cbuf, d->N, (long)W.Cpad, labels, W.ty, W.tysum);
   FRX_LAUNCH_CHECK();
   return FRX_OK;
 }
@@ -894,6 +1009,8 @@ extern "C" int frx_head_fwd(int device, frx_stream_t stream, const frx_head_desc
                             size_t ws_bytes, float* cos_s, float* logits, float* norms, float* loss,
                             float* lse, int32_t* topk) {
   if (int rc = frx_head_fwd_cos(device, stream, d, x, w, labels, ws, ws_bytes, nullptr)) return rc;
+  if (d->kind == FRX_VPL)
+    if (int rc = frx_head_vpl_prepare(device, stream, d, x, labels, state_t, ws, ws_bytes)) return rc;
   return frx_head_fwd_loss(device, stream, d, labels, state_t, nullptr, 0, ws, ws_bytes, cos_s, logits,
                            norms, loss, lse, topk);
 }
@@ -920,6 +1037,12 @@ static int head_bwd_impl(int device, frx_stream_t stream, const frx_head_desc* d
 #undef FRX_GRAD
   FRX_LAUNCH_CHECK();
   const bool cd = w_is_cd(d->kind);
+  const bool vpl = vpl_memory_on(d);
+  if (vpl) {
+    hipLaunchKernelGGL(k_vpl_split, dim3(d->N), dim3(256), 0, st, W.gbuf, W.gbuf2,
+                       (const float*)(state_t + (size_t)d->C * d->D), labels, d->C, W.Cpad, d->p[0]);
+    FRX_LAUNCH_CHECK();
+  }
   // dX^ [N,D] = dC [N,C] . W^   (K = C: split so the grid fills the chip)
   {
     // (a kernel, not hipMemsetAsync: inside a replayed hipGraph the memset NODE intermittently filled this buffer with
@@ -935,6 +1058,10 @@ static int head_bwd_impl(int device, frx_stream_t stream, const frx_head_desc* d
     int ksplit = tiles >= 512 ? 1 : cdiv(1024, tiles);
     ksplit = ksplit > cdiv(d->C, 64) ? cdiv(d->C, 64) : ksplit;
     if (int rc = launch_gemm(st, g, ksplit)) return rc;
+    if (vpl) {                       // + (dC * a*lamda, non-target) . M^   into the same accumulator
+      g.A = W.gbuf2; g.a_kscale = W.minv; g.B = state_t;
+      if (int rc = launch_gemm(st, g, ksplit)) return rc;
+    }
   }
   hipLaunchKernelGGL(k_norm_bwd_rows, dim3(cdiv(d->N, 4)), dim3(256), 0, st, x, (const float*)W.dxh,
                      (const float*)W.xinv, (d->kind == FRX_SPHERE || d->kind == FRX_MAG) ? (const float*)W.dn : (const float*)nullptr,

@@ -57,6 +57,7 @@ _SIGS = {
     "frx_head_bwd": (C.c_int, [C.c_int, _P, C.POINTER(HeadDesc), _P, _P, _P, _P, _P, _P, C.c_size_t,
                                _P, _P, C.c_int]),
     "frx_head_aux": (C.c_int, [C.c_int, _P, C.POINTER(HeadDesc), _P, _P, C.c_size_t, _P, _P]),
+    "frx_head_vpl_prepare": (C.c_int, [C.c_int, _P, C.POINTER(HeadDesc), _P, _P, _P, _P, C.c_size_t]),
     "frx_conv_stat_rows": (C.c_int, [C.POINTER(ConvDesc)]),
     "frx_stem_padded_dims": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "frx_conv_fwd": (C.c_int, [C.c_int, _P, C.POINTER(ConvDesc), _P, _P, _P, _P, C.c_int, _P, _P, C.c_int, _P]),

@@ -10,8 +10,8 @@ from . import _lib
 from ._lib import FrxError, HeadDesc, check
 
 ARC, COS, SPHERE, CURR = 0, 1, 2, 3
-MV_AM, MV_ARC, ADA, ELASTIC_ARC, ELASTIC_COS, MAG = 4, 5, 6, 7, 8, 9       # include/frx.h frx_head_kind
-W_CD_KINDS = (ARC, SPHERE, MV_AM, MV_ARC)       # heads whose parameter is `weight` [C, D]; the others hold `kernel` [D, C]
+MV_AM, MV_ARC, ADA, ELASTIC_ARC, ELASTIC_COS, MAG, VPL = 4, 5, 6, 7, 8, 9, 10       # include/frx.h frx_head_kind
+W_CD_KINDS = (ARC, SPHERE, MV_AM, MV_ARC, VPL)       # heads whose parameter is `weight` [C, D]; the others hold `kernel` [D, C]
 
 # Optional per-launch timing (bench.py roofline leg): when PROFILER is a list, the GEMM-class entry
 # points bracket their launch with events on the current stream and append
@@ -75,7 +75,8 @@ class HeadContext:
 
     def __init__(self, kind, N, D, C_, s, m, momentum=0.01, device=None, p=(0.0, 0.0, 0.0, 0.0), flags=0, lambda_g=0.0):
         """p / flags: per-kind parameters of frx_head_desc (MV: mv_weight; ADA: h, t_alpha; MAG: l_margin, u_margin,
-        l_a, u_a and flags bit 0 = easy_margin).  lambda_g: MagFace's loss_g weight for the fused backward."""
+        l_a, u_a and flags bit 0 = easy_margin; VPL: lamda, delta and flags bit 0 = easy_margin, bit 1 = memory in use).
+        lambda_g: MagFace's loss_g weight for the fused backward."""
         p = tuple(float(v) for v in p) + (0.0,) * (4 - len(p))
         self.desc = HeadDesc(kind, N, D, C_, s, m, momentum, float(lambda_g) if kind == MAG else 0.0,
                              (C.c_float * 4)(*p), int(flags), 0)
@@ -118,6 +119,9 @@ def head_forward(ctx: HeadContext, x, w, labels, state_t=None, lamb=0.0, want_lo
         tys = torch.empty(1, device=x.device)
         check(L.frx_head_fwd_cos(dev, st, C.byref(ctx.desc), _p(x), _p(w), _p(labels), _p(ctx.ws), ctx.nbytes,
                                  _p(tys)), "frx_head_fwd_cos")
+        if ctx.desc.kind == VPL:
+            check(L.frx_head_vpl_prepare(dev, st, C.byref(ctx.desc), _p(x), _p(labels), _p(state_t), _p(ctx.ws), ctx.nbytes),
+                  "frx_head_vpl_prepare")
         count = ty_allreduce(tys)
         check(L.frx_head_fwd_loss(dev, st, C.byref(ctx.desc), _p(labels), _p(state_t), _p(tys), int(count),
                                   _p(ctx.ws), ctx.nbytes, _p(o["cos_s"]), _p(o["logits"]), _p(o["norms"]),

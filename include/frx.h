@@ -39,9 +39,10 @@ enum frx_dtype { FRX_F32 = 0, FRX_BF16 = 1 };
 
 /* head kinds (main_code/utils/criterion.py): ArcFace:232, CosFace:137, SphereFace:12, CurricularFace:491, and the
  * SURVEY 8(f)-3 widening: MV_Softmax:327 ('am' / 'arc' margin types), AdaFace:795, ElasticArcFace:1054,
- * ElasticCosFace:951, MagFace:1178 */
+ * ElasticCosFace:951, MagFace:1178, VPLArcFace:619 */
 enum frx_head_kind { FRX_ARC = 0, FRX_COS = 1, FRX_SPHERE = 2, FRX_CURR = 3,
-                     FRX_MV_AM = 4, FRX_MV_ARC = 5, FRX_ADA = 6, FRX_ELASTIC_ARC = 7, FRX_ELASTIC_COS = 8, FRX_MAG = 9 };
+                     FRX_MV_AM = 4, FRX_MV_ARC = 5, FRX_ADA = 6, FRX_ELASTIC_ARC = 7, FRX_ELASTIC_COS = 8, FRX_MAG = 9,
+                     FRX_VPL = 10 };
 
 /* ---------------------------------------------------------------- diagnostics */
 int frx_version(void);
@@ -71,8 +72,10 @@ typedef struct frx_head_desc {
                                 frx_head_bwd_dlogits: the upstream gradient dL/dloss_g (0 leaves loss_g out) */
   float p[4];        /* MV_*: p[0] = mv_weight (criterion.py:341)
                         ADA:  p[0] = h, p[1] = t_alpha (criterion.py:805-807)
-                        MAG:  p[0] = l_margin, p[1] = u_margin, p[2] = l_a, p[3] = u_a (criterion.py:1188-1191) */
-  int32_t flags;     /* MAG: bit 0 = easy_margin (criterion.py:1187) */
+                        MAG:  p[0] = l_margin, p[1] = u_margin, p[2] = l_a, p[3] = u_a (criterion.py:1188-1191)
+                        VPL:  p[0] = lamda, p[1] = delta (criterion.py:632-633) */
+  int32_t flags;     /* MAG, VPL: bit 0 = easy_margin (criterion.py:1187, 631)
+                        VPL: bit 1 = norm_training_flag, the memory is in use (criterion.py:671-679) */
   int32_t reserved;
 } frx_head_desc;
 
@@ -81,6 +84,7 @@ typedef struct frx_head_desc {
  *   ADA           [2]  batch_mean, batch_std (criterion.py:838-839), EMA-updated in place before use (:873-877)
  *   ELASTIC_*     [N]  this step's per-row margins, already sampled and clamped by the caller
  *                      (torch.normal + clamp, criterion.py:1002-1004 / 1113-1115; read only)
+ *   VPL           [C*D + C]  `mem` [C,D] then `life` [C] (criterion.py:660-661), both updated by frx_head_vpl_prepare
  *   other kinds   may be NULL */
 
 size_t frx_head_workspace_bytes(const frx_head_desc* d);
@@ -102,6 +106,11 @@ int frx_head_fwd_loss(int device, frx_stream_t stream, const frx_head_desc* d, c
                       float* state_t, const float* ty_sum, int64_t ty_count, void* ws, size_t ws_bytes,
                       float* cos_s, float* logits, float* norms, float* loss, float* lse,
                       int32_t* topk);
+/* VPL only, between frx_head_fwd_cos and frx_head_fwd_loss (frx_head_fwd calls it itself): per-class mean of the batch's
+ * raw features into `mem`, `life` = delta for those classes, life -= 1 for all classes, cosine against the normalised
+ * memory and the lamda blend of criterion.py:699-722 written over the cosines in the workspace (flags bit 1 clear: no-op). */
+int frx_head_vpl_prepare(int device, frx_stream_t stream, const frx_head_desc* d, const float* x, const int64_t* labels,
+                         float* state_t, void* ws, size_t ws_bytes);
 /* After frx_head_fwd_loss: loss_g [1] (MAG: mean(x_norm / u_a^2 + 1 / x_norm), criterion.py:1235-1239; 0 for other
  * kinds) and, optionally, the per-row parameter the epilogue used, row_param [N]: ADA margin_scaler (:879-880), MAG
  * ada_margin (:1229-1233), ELASTIC_* the margins passed in; zeros otherwise.  For MAG the `norms` output of

@@ -13,6 +13,7 @@ Follows the reference (paths relative to /root/reference/main_code):
   ElasticArcFace utils/criterion.py:1089-1145 (ctor :1061-1083; plus=False)
   ElasticCosFace utils/criterion.py:982-1021  (ctor :955-976; plus=False)
   MagFace        utils/criterion.py:1241-1291 (ctor :1185-1222)
+  VPLArcFace     utils/criterion.py:686-752   (ctor :626-674)
   CE             utils/model_utils.py:556,179 (nn.CrossEntropyLoss, mean)
   accuracy       utils/metrics.py:3-16
 Pinned by tests/golden/heads_*.npz (generated from the reference import: make_golden.py, make_golden_heads2.py).
@@ -25,9 +26,9 @@ from dataclasses import dataclass, field
 import numpy as np
 
 ARC, COS, SPHERE, CURR = 0, 1, 2, 3
-MV_AM, MV_ARC, ADA, ELASTIC_ARC, ELASTIC_COS, MAG = 4, 5, 6, 7, 8, 9
+MV_AM, MV_ARC, ADA, ELASTIC_ARC, ELASTIC_COS, MAG, VPL = 4, 5, 6, 7, 8, 9, 10
 KIND_NAMES = {ARC: "arcface", COS: "cosface", SPHERE: "sphereface", CURR: "curricular", MV_AM: "mv_am", MV_ARC: "mv_arc",
-              ADA: "adaface", ELASTIC_ARC: "elastic_arc", ELASTIC_COS: "elastic_cos", MAG: "magface"}
+              ADA: "adaface", ELASTIC_ARC: "elastic_arc", ELASTIC_COS: "elastic_cos", MAG: "magface", VPL: "vpl_arcface"}
 
 NORM_EPS = 1e-12  # F.normalize default eps
 
@@ -40,6 +41,8 @@ class HeadState:
     t: float = 0.0           # CurricularFace.t buffer (criterion.py:517,572)
     batch_mean: float = 20.0   # AdaFace buffers (criterion.py:838-839)
     batch_std: float = 100.0
+    mem: object = None         # VPLArcFace buffers (criterion.py:660-661): [C,D] and [C]; created on first use
+    life: object = None
 
 
 @dataclass
@@ -61,6 +64,9 @@ class HeadHyper:
     l_a: float = 10.0
     u_a: float = 110.0
     easy_margin: bool = False
+    lamda: float = 0.15      # VPLArcFace (config.py:43-44)
+    delta: float = 100.0
+    memory_on: bool = True   # VPLArcFace.norm_training_flag (criterion.py:671)
 
     @staticmethod
     def default(kind: int) -> "HeadHyper":
@@ -83,13 +89,15 @@ class HeadHyper:
             return HeadHyper(ELASTIC_COS, s=64.0, m=0.35)
         if kind == MAG:                                  # config.py:65-70
             return HeadHyper(MAG, s=64.0, m=0.0)
+        if kind == VPL:                                  # config.py:40-44
+            return HeadHyper(VPL, s=64.0, m=0.5, easy_margin=False, lamda=0.15, delta=100.0)
         raise ValueError(kind)
 
 
 def weight_is_cd(kind: int) -> bool:
     """True when the class weight is stored [C, D] (ArcFace/SphereFace 'weight'),
     False when stored [D, C] (CosFace/CurricularFace 'kernel').  SURVEY H7."""
-    return kind in (ARC, SPHERE, MV_AM, MV_ARC)
+    return kind in (ARC, SPHERE, MV_AM, MV_ARC, VPL)
 
 
 @dataclass
@@ -267,6 +275,37 @@ def head_forward_backward(kind, x, w, labels, hyper: HeadHyper, state: HeadState
         cos_s = c * dt(hyper.s)
         pass_clamp = (c_raw >= lo) & (c_raw <= hi)
         extra.update(row_param=mrow[:, 0].copy())
+    elif kind == VPL:
+        lo, hi = dt(-1) + dt(1e-7), dt(1) - dt(1e-7)
+        vpl_al = None
+        blend = c_raw                                              # cosine_weight (:694-695)
+        if hyper.memory_on:
+            if state.mem is None:
+                state.mem, state.life = np.zeros((C, D), dtype=dtype), np.zeros(C, dtype=dtype)
+            for cls in np.unique(labels):                          # :703-709 (raw features, per-class mean)
+                state.mem[cls] = x[labels == cls].mean(axis=0, dtype=dtype)
+                state.life[cls] = hyper.delta
+            state.life = state.life - 1                            # :712
+            vpl_al = ((state.life > 0).astype(dtype) * dt(hyper.lamda))[None, :]       # active * lamda, [1,C]
+            mh, _ = _normalize_rows(state.mem.astype(dtype), dt)   # :716
+            vpl_mh = mh
+            c_mem = (xh @ mh.T).astype(dtype)                      # :717
+            cos1 = (dt(1) - vpl_al) * c_raw + vpl_al * c_mem       # :720
+            cos2 = (dt(1) - vpl_al) * c_raw + vpl_al * dt(1.0)     # :721
+            blend = onehot * cos2 + (dt(1.0) - onehot) * cos1      # :722
+        c = np.clip(blend, lo, hi)                                 # :730
+        cos_m, sin_m = dt(math.cos(hyper.m)), dt(math.sin(hyper.m))
+        th, mm = dt(math.cos(math.pi - hyper.m)), dt(math.sin(math.pi - hyper.m) * hyper.m)
+        sine = np.sqrt(dt(1.0) - c * c + dt(1e-9))                 # :734
+        phi = c * cos_m - sine * sin_m
+        if hyper.easy_margin:
+            on, off = c > 0, c                                     # :738
+        else:
+            on, off = c > th, c - mm                               # :740
+        z = (onehot * np.where(on, phi, off) + (dt(1.0) - onehot) * c) * dt(hyper.s)   # :743-744
+        cos_s = c * dt(hyper.s)
+        pass_clamp = (blend >= lo) & (blend <= hi)
+        dzdc = dt(hyper.s) * np.where(onehot > 0, np.where(on, cos_m + sin_m * c / sine, dt(1)), dt(1))
     elif kind == MAG:
         lo, hi = dt(-1) + dt(1e-7), dt(1) - dt(1e-7)
         la, ua = dt(hyper.l_a), dt(hyper.u_a)
@@ -322,7 +361,12 @@ def head_forward_backward(kind, x, w, labels, hyper: HeadHyper, state: HeadState
     if need_grad:
         g = (e / se - onehot) / dt(N)                              # dL/dz
         dc = g * dzdc * pass_clamp                                 # dL/dc_raw
+        if kind == VPL and hyper.memory_on:                        # through the blend: weight path and memory path
+            dc_mem = dc * vpl_al * (dt(1.0) - onehot)
+            dc = dc * (dt(1) - vpl_al)
         dxh = dc @ wh                                              # [N,D]
+        if kind == VPL and hyper.memory_on:
+            dxh = dxh + dc_mem @ vpl_mh
         dwh = dc.T @ xh                                            # [C,D]
         dx = (dxh - xh * (xh * dxh).sum(axis=1, keepdims=True)) / np.maximum(xnorm, dt(NORM_EPS))
         dwc = (dwh - wh * (wh * dwh).sum(axis=1, keepdims=True)) / np.maximum(wnorm, dt(NORM_EPS))

@@ -104,8 +104,8 @@ class TorchHead(nn.Module):
         shape = (num_classes, feat_dim) if H.weight_is_cd(kind) else (feat_dim, num_classes)
         self.weight = nn.Parameter(torch.empty(shape))
         self.loss_g, self.row_margin, self.next_margin, self.elastic_std = 0, None, None, 0.0125
-        if kind in (H.ARC, H.SPHERE):
-            nn.init.xavier_uniform_(self.weight)                       # criterion.py:244,37
+        if kind in (H.ARC, H.SPHERE, H.VPL):
+            nn.init.xavier_uniform_(self.weight)                       # criterion.py:244,37,657
         elif kind in (H.COS, H.MV_AM, H.MV_ARC, H.ADA, H.MAG):
             self.weight.data.uniform_(-1, 1).renorm_(2, 1, 1e-5).mul_(1e5)  # :152,367,833,1216
         else:
@@ -169,6 +169,28 @@ class TorchHead(nn.Module):
                 return c * hy.s, (c - onehot * margin) * hy.s
             fin = (c[rows, labels].acos().view(-1, 1) + margin).clamp(0, math.pi).cos()
             return c * hy.s, c.scatter(1, labels.view(-1, 1), fin) * hy.s
+        if self.kind == H.VPL:                                         # criterion.py:699-744
+            st = self.state
+            if hy.memory_on:
+                with torch.no_grad():
+                    if st.mem is None:
+                        st.mem, st.life = torch.zeros_like(self.weight), torch.zeros(self.weight.shape[0])
+                    for cls in torch.unique(labels):
+                        st.mem[cls] = x.detach()[labels == cls].mean(dim=0)
+                        st.life[cls] = hy.delta
+                    st.life = st.life - 1
+                    act = (st.life > 0).float().unsqueeze(0)
+                c_mem = F.linear(F.normalize(x), F.normalize(st.mem, dim=1))
+                cos1 = (1 - act * hy.lamda) * c + act * hy.lamda * c_mem
+                cos2 = (1 - act * hy.lamda) * c + act * hy.lamda * 1.0
+                c = onehot * cos2 + (1.0 - onehot) * cos1
+            c = c.clamp(-1 + 1e-7, 1 - 1e-7)
+            phi = c * math.cos(hy.m) - torch.sqrt(1.0 - c ** 2 + 1e-9) * math.sin(hy.m)
+            if hy.easy_margin:
+                phi = torch.where(c > 0, phi, c)
+            else:
+                phi = torch.where(c > math.cos(math.pi - hy.m), phi, c - math.sin(math.pi - hy.m) * hy.m)
+            return c * hy.s, (onehot * phi + (1.0 - onehot) * c) * hy.s
         if self.kind == H.MAG:                                         # criterion.py:1245-1289
             xn = torch.norm(x, p=2, dim=1, keepdim=True).clamp(hy.l_a, hy.u_a)
             self.loss_g = torch.mean(1 / (hy.u_a ** 2) * xn + 1 / xn)

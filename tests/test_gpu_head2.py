@@ -22,6 +22,8 @@ def kind_params(kind, hyper):
         return (hyper.h, hyper.t_alpha), 0
     if kind == H.MAG:
         return (hyper.l_margin, hyper.u_margin, hyper.l_a, hyper.u_a), int(hyper.easy_margin)
+    if kind == H.VPL:
+        return (hyper.lamda, hyper.delta), int(hyper.easy_margin) | (2 if hyper.memory_on else 0)
     return (), 0
 
 
@@ -40,6 +42,10 @@ def run(kind, x, w, y, hyper, state, margins=None, lambda_g=0.0, dlogits_mode=Fa
         st = torch.tensor([state.batch_mean, state.batch_std], dtype=torch.float32, device=dev)
     elif kind in (H.ELASTIC_ARC, H.ELASTIC_COS):
         st = torch.from_numpy(np.asarray(margins, dtype=np.float32)).to(dev)
+    elif kind == H.VPL:                      # [mem | life]
+        mem = np.zeros((Cc, D), np.float32) if state.mem is None else state.mem
+        life = np.zeros(Cc, np.float32) if state.life is None else state.life
+        st = torch.from_numpy(np.concatenate([mem.reshape(-1), life]).astype(np.float32)).to(dev)
     o = ops.head_forward(ctx, xd, wd, yd, state_t=st, want_logits=True)
     if dlogits_mode:       # autograd-style: upstream gradient of the mean CE w.r.t. the returned logits
         z = o["logits"].double()
@@ -80,6 +86,10 @@ def test_head_vs_reference_golden(golden_dir, name, tag):
     if kind == H.ADA:
         assert st_after[0] == pytest.approx(float(g[f"{tag}_post_batch_mean"]), rel=1e-5)
         assert st_after[1] == pytest.approx(float(g[f"{tag}_post_batch_std"]), rel=1e-5)
+    if kind == H.VPL:
+        Cc, D = g[f"{tag}_w"].shape
+        np.testing.assert_allclose(st_after[:Cc * D].reshape(Cc, D), g[f"{tag}_post_mem"], rtol=1e-5, atol=1e-6)
+        np.testing.assert_array_equal(st_after[Cc * D:], g[f"{tag}_post_life"])
 
 
 @pytest.mark.parametrize("name", list(CASES))
@@ -101,8 +111,15 @@ def test_head_vs_oracle_seeded(name, shape):
     margins = None
     if kind in (H.ELASTIC_ARC, H.ELASTIC_COS):
         margins = np.clip(rng.normal(hy.m, 0.0125, N), hy.m - 0.0125, hy.m + 0.0125).astype(np.float32)
-    st = H.HeadState(batch_mean=21.5, batch_std=9.0)
-    ref = H.head_forward_backward(kind, x, w, y, hy, H.HeadState(batch_mean=21.5, batch_std=9.0), dtype=np.float64,
+    def fresh_state():
+        st = H.HeadState(batch_mean=21.5, batch_std=9.0)
+        if kind == H.VPL:                   # a warm memory: half of the classes alive with random centres
+            r2 = np.random.RandomState(7)
+            st.mem = r2.randn(Cc, D).astype(np.float32)
+            st.life = np.where(r2.rand(Cc) < 0.5, 5.0, -3.0).astype(np.float32)
+        return st
+    st = fresh_state()
+    ref = H.head_forward_backward(kind, x, w, y, hy, fresh_state(), dtype=np.float64,
                                   row_margin=margins, lambda_g=20.0)
     o, dx, dw, _ = run(kind, x, w, y, hy, st, margins, lambda_g=20.0)
     np.testing.assert_allclose(o["logits"].cpu().numpy(), ref.logits, atol=LOGIT_TOL, rtol=0)
@@ -114,9 +131,8 @@ def test_head_vs_oracle_seeded(name, shape):
     np.testing.assert_allclose(dx, ref.dx, atol=1e-3 * np.abs(ref.dx).max(), rtol=0)
     np.testing.assert_allclose(dw, ref.dw, atol=1e-3 * np.abs(ref.dw).max(), rtol=0)
     # the autograd-style entry (arbitrary dL/dlogits) gives the CE part of the same gradient
-    ref0 = H.head_forward_backward(kind, x, w, y, hy, H.HeadState(batch_mean=21.5, batch_std=9.0), dtype=np.float64,
-                                   row_margin=margins, lambda_g=0.0)
-    _, dx2, dw2, _ = run(kind, x, w, y, hy, H.HeadState(batch_mean=21.5, batch_std=9.0), margins, dlogits_mode=True)
+    ref0 = H.head_forward_backward(kind, x, w, y, hy, fresh_state(), dtype=np.float64, row_margin=margins, lambda_g=0.0)
+    _, dx2, dw2, _ = run(kind, x, w, y, hy, fresh_state(), margins, dlogits_mode=True)
     np.testing.assert_allclose(dx2, ref0.dx, atol=1e-3 * np.abs(ref0.dx).max(), rtol=0)
     np.testing.assert_allclose(dw2, ref0.dw, atol=1e-3 * np.abs(ref0.dw).max(), rtol=0)
 

@@ -9,7 +9,7 @@ import pytest
 from oracle import heads as H
 
 CASES = {"mv_am": H.MV_AM, "mv_arc": H.MV_ARC, "adaface": H.ADA, "elastic_arc": H.ELASTIC_ARC,
-         "elastic_cos": H.ELASTIC_COS, "magface": H.MAG, "magface_easy": H.MAG}
+         "elastic_cos": H.ELASTIC_COS, "magface": H.MAG, "magface_easy": H.MAG, "vpl_arcface": H.VPL}
 
 
 def load_case(golden_dir, name, tag):
@@ -19,6 +19,8 @@ def load_case(golden_dir, name, tag):
     if name == "magface_easy":
         hyper.easy_margin = True
     st = H.HeadState(batch_mean=float(g[f"{tag}_pre_batch_mean"]), batch_std=float(g[f"{tag}_pre_batch_std"]))
+    if kind == H.VPL:
+        st.mem, st.life = g[f"{tag}_pre_mem"].copy(), g[f"{tag}_pre_life"].copy()
     margins = g[f"{tag}_row_margin"] if f"{tag}_row_margin" in g.files else None
     return g, kind, hyper, st, margins
 
@@ -60,6 +62,9 @@ def test_head_matches_reference(golden_dir, name, tag):
     if kind == H.ADA:
         assert st.batch_mean == pytest.approx(float(g[f"{tag}_post_batch_mean"]), rel=1e-5)
         assert st.batch_std == pytest.approx(float(g[f"{tag}_post_batch_std"]), rel=1e-5)
+    if kind == H.VPL:
+        np.testing.assert_allclose(st.mem, g[f"{tag}_post_mem"], rtol=1e-6, atol=1e-7)
+        np.testing.assert_array_equal(st.life, g[f"{tag}_post_life"])
     assert float(g[f"{tag}_onehot_sum"]) == n
 
 
@@ -84,6 +89,12 @@ def test_fixture_exercises_the_branches(golden_dir):
     assert (out.extra["row_param"] > 0).any() and (out.extra["row_param"] < 0).any()
     g = np.load(os.path.join(golden_dir, "heads_elastic_arc.npz"))
     assert np.all(np.abs(g["fresh_row_margin"] - 0.5) <= 0.0125 + 1e-7) and g["fresh_row_margin"].std() > 0
+    # VPL: in the warm state classes of EARLIER batches are still alive, so the memory path acts on non-targets,
+    # and some classes have never been seen (inactive columns)
+    g = np.load(os.path.join(golden_dir, "heads_vpl_arcface.npz"))
+    alive_before = g["warm_pre_life"] > 1
+    assert alive_before.any() and not set(np.where(alive_before)[0]) <= set(g["warm_y"].tolist())
+    assert (g["warm_post_life"] <= 0).any() and len(set(g["warm_y"].tolist())) < len(g["warm_y"])
 
 
 @pytest.mark.parametrize("name", list(CASES))
@@ -102,7 +113,7 @@ def test_torch_head_matches_closed_form():
     import torch.nn.functional as F
     from oracle.resnet50 import TorchHead
     rng = np.random.RandomState(0)
-    for kind in (H.MV_AM, H.MV_ARC, H.ADA, H.ELASTIC_ARC, H.ELASTIC_COS, H.MAG):
+    for kind in (H.MV_AM, H.MV_ARC, H.ADA, H.ELASTIC_ARC, H.ELASTIC_COS, H.MAG, H.VPL):
         torch.manual_seed(kind)
         hy = H.HeadHyper.default(kind)
         th = TorchHead(kind, 64, 40, hy)
