@@ -121,7 +121,7 @@ def run():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
     ap.add_argument("--classes", type=int, default=10575)
     ap.add_argument("--head", default="arcface",
-                    help="arcface | cosface | sphereface | curricular | mv_am | mv_arc | adaface | elastic_arc | elastic_cos | magface")
+                    help="arcface | cosface | sphereface | curricular | mv_am | mv_arc | adaface | elastic_arc | elastic_cos | magface | vpl_arcface")
     ap.add_argument("--lambda-g", type=float, default=0.0, help="MagFace: weight of loss_g (model_utils.py:180, 482)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     ap.add_argument("--lr", type=float, default=0.005)

@@ -620,14 +620,17 @@ class ResNet50Engine:
 
 HEAD_KINDS = {"arcface": ops.ARC, "cosface": ops.COS, "sphereface": ops.SPHERE, "curricular": ops.CURR,
               "mv_am": ops.MV_AM, "mv_arc": ops.MV_ARC, "adaface": ops.ADA, "elastic_arc": ops.ELASTIC_ARC,
-              "elastic_cos": ops.ELASTIC_COS, "magface": ops.MAG}
+              "elastic_cos": ops.ELASTIC_COS, "magface": ops.MAG, "vpl_arcface": ops.VPL}
 # (s, m) per head: main_code/utils/config.py:16-70.  SphereFace ignores s (criterion.py:119-123); the elastic heads
 # sample their margin around m; MagFace derives it from the feature norm.
 HEAD_DEFAULTS = {ops.ARC: (64.0, 0.5), ops.COS: (64.0, 0.35), ops.SPHERE: (1.0, 2.0), ops.CURR: (64.0, 0.5),
                  ops.MV_AM: (32.0, 0.35), ops.MV_ARC: (32.0, 0.35), ops.ADA: (64.0, 0.4), ops.ELASTIC_ARC: (64.0, 0.5),
-                 ops.ELASTIC_COS: (64.0, 0.35), ops.MAG: (64.0, 0.0)}
+                 ops.ELASTIC_COS: (64.0, 0.35), ops.MAG: (64.0, 0.0), ops.VPL: (64.0, 0.5)}
 # frx_head_desc::p defaults: MV mv_weight (config.py:30); ADA h, t_alpha (:49-50); MAG l_margin, u_margin, l_a, u_a (:67-70)
-HEAD_P_DEFAULTS = {ops.MV_AM: (1.12,), ops.MV_ARC: (1.12,), ops.ADA: (0.333, 0.99), ops.MAG: (0.45, 0.8, 10.0, 110.0)}
+# VPL lamda, delta (:43-44)
+HEAD_P_DEFAULTS = {ops.MV_AM: (1.12,), ops.MV_ARC: (1.12,), ops.ADA: (0.333, 0.99), ops.MAG: (0.45, 0.8, 10.0, 110.0),
+                   ops.VPL: (0.15, 100.0)}
+HEAD_FLAG_DEFAULTS = {ops.VPL: 2}           # VPL: memory in use (norm_training_flag), easy_margin off (config.py:42)
 ELASTIC_KINDS = (ops.ELASTIC_ARC, ops.ELASTIC_COS)
 
 
@@ -635,7 +638,7 @@ class FaceEngine:
     """Backbone + margin head + fused SGD: one training step = forward, CE, backward, update."""
 
     def __init__(self, kind, num_classes, batch, dtype=BF16, device="cuda:0", s=None, m=None, momentum=0.01, seed=None,
-                 share=None, head_p=None, head_flags=0, lambda_g=0.0, elastic_std=0.0125):
+                 share=None, head_p=None, head_flags=None, lambda_g=0.0, elastic_std=0.0125):
         self.kind = HEAD_KINDS[kind] if isinstance(kind, str) else kind
         self.C, self.N = num_classes, batch
         ds, dm = HEAD_DEFAULTS[self.kind]
@@ -646,11 +649,15 @@ class FaceEngine:
         self.device = self.net.device
         self.head_p = tuple(HEAD_P_DEFAULTS.get(self.kind, ()) if head_p is None else head_p)
         self.elastic_std = float(elastic_std)
+        head_flags = HEAD_FLAG_DEFAULTS.get(self.kind, 0) if head_flags is None else head_flags
         self.head = ops.HeadContext(self.kind, batch, FEATURE_DIM, num_classes, self.s, self.m, momentum, device=self.device,
                                     p=self.head_p, flags=head_flags, lambda_g=lambda_g)
         # Head state (include/frx.h, `state_t`): CurricularFace's `t` [1] (criterion.py:517); AdaFace's batch_mean /
-        # batch_std [2] (:838-839), shared between batch sizes like `t`; the elastic heads' per-row margins [N].
-        if self.kind in ELASTIC_KINDS:
+        # batch_std [2] (:838-839), shared between batch sizes like `t`; the elastic heads' per-row margins [N];
+        # VPL-ArcFace's class memory `mem` [C,512] followed by `life` [C] (:660-661), shared as well.
+        if self.kind == ops.VPL:
+            self.t = torch.zeros(num_classes * FEATURE_DIM + num_classes, device=self.device) if share is None else share.t
+        elif self.kind in ELASTIC_KINDS:
             self.t = torch.full((batch,), float(self.m), device=self.device)
         elif self.kind == ops.ADA:
             self.t = torch.tensor([20.0, 100.0], device=self.device) if share is None else share.t
@@ -686,7 +693,7 @@ class FaceEngine:
         if seed is not None:
             g.manual_seed(seed + 1)
         C, D = self.C, FEATURE_DIM
-        if self.kind in (ops.ARC, ops.SPHERE):      # xavier_uniform_ on [C,D] (criterion.py:244,37)
+        if self.kind in (ops.ARC, ops.SPHERE, ops.VPL):      # xavier_uniform_ on [C,D] (criterion.py:244,37,657)
             bound = math.sqrt(6.0 / (C + D))
             w = (torch.rand(C, D, generator=g) * 2 - 1) * bound
         elif self.kind in (ops.MV_AM, ops.MV_ARC):   # same expression on [C,D] (criterion.py:367)

@@ -112,6 +112,12 @@ class NativeFaceNet(nn.Module):
         self._engines[n] = eng
         return eng
 
+    def _sync_head_flags(self, eng):
+        """heads whose flags change at run time (VPL-ArcFace's change_training_mode, criterion.py:676-679)"""
+        f = getattr(self.head, "frx_flags", None)
+        if f is not None:
+            eng.head.desc.flags = int(f)
+
     def _adopt(self, eng):
         """first engine: load the module's current tensors, then alias every Parameter / buffer to it"""
         net = eng.net
@@ -122,6 +128,8 @@ class NativeFaceNet(nn.Module):
             eng.t.copy_(self.head.t.detach().to(eng.device))
         elif eng.kind == ops.ADA:
             eng.t.copy_(torch.cat([self.head.batch_mean.detach().view(1), self.head.batch_std.detach().view(1)]).to(eng.device))
+        elif eng.kind == ops.VPL:
+            eng.t.copy_(torch.cat([self.head.mem.detach().reshape(-1), self.head.life.detach().reshape(-1)]).to(eng.device))
         mods = dict(self.backbone.named_modules())
 
         def sub(dotted):
@@ -149,6 +157,11 @@ class NativeFaceNet(nn.Module):
         elif eng.kind == ops.ADA:                      # the two EMA buffers live in the engine's head state
             self.head.batch_mean, self.head.batch_std = eng.t[0:1], eng.t[1:2]
             self.head.t = self.head.t.to(eng.device)
+        elif eng.kind == ops.VPL:                      # class memory and its life counters live in the engine's head state
+            cd = eng.C * E.FEATURE_DIM
+            self.head.mem, self.head.life = eng.t[:cd].view(eng.C, E.FEATURE_DIM), eng.t[cd:]
+            for k in ("cos_m", "sin_m", "th", "mm"):
+                setattr(self.head, k, getattr(self.head, k).to(eng.device))
         self._primary = eng
         self._param_list = list(self.parameters())
         self._synced_version = self._version_sum()
@@ -194,6 +207,7 @@ class NativeFaceNet(nn.Module):
     def forward(self, x, labels=None):
         eng = self._engine_for(x.shape[0], x.device)
         self._resync_if_touched()
+        self._sync_head_flags(eng)
         if not self.training:
             with torch.no_grad():
                 eng.net.training = False

@@ -1,7 +1,7 @@
 """Margin heads and model wrappers with the reference's class names, constructor signatures,
 attribute names (= state-dict keys) and forward contract (main_code/utils/criterion.py:12-135,
 137-230, 232-325, 491-617; and, SURVEY 8(f)-3, MV_Softmax :327-489, AdaFace :795-949, ElasticCosFace :951-1052,
-ElasticArcFace :1054-1176, MagFace :1178-1329).  The arithmetic runs in libfrx (frx/ops.py, csrc/head.hip); these
+ElasticArcFace :1054-1176, MagFace :1178-1329, VPLArcFace :619-793).  The arithmetic runs in libfrx (frx/ops.py, csrc/head.hip); these
 classes hold parameters and per-head state only.
 
 Training-mode forward of a *Net returns ([cos_s, logits], norms, loss_g, one_hot) -- `logits`
@@ -15,7 +15,7 @@ from frx import ops
 from frx.module import NativeFaceNet
 
 from .backbones import get_backbone
-from .config import (COMPUTE_DTYPE, EASY_MARGIN_mag, FEATURE_DIM, H_ada, L_A_mag, L_MARGIN_mag, M_ada, M_arc, M_cos,
+from .config import (COMPUTE_DTYPE, DELTA_vpl, EASY_MARGIN_mag, EASY_MARGIN_vpl, LAMDA_vpl, M_vpl, S_vpl, FEATURE_DIM, H_ada, L_A_mag, L_MARGIN_mag, M_ada, M_arc, M_cos,
                      M_curricular, M_elastic_arc, M_elastic_cos, M_mv, M_sphere, MARGIN_TYPE_mv, MOMENTUM_curricular,
                      PLUS_elastic_arc, PLUS_elastic_cos, S_ada, S_arc, S_cos, S_curricular, S_elastic_arc, S_elastic_cos,
                      S_mag, S_mv, STD_elastic_arc, STD_elastic_cos, T_ALPHA_ada, U_A_mag, U_MARGIN_mag, WEIGHT_mv)
@@ -209,6 +209,38 @@ class MagFace(_HeadBase):
         return torch.mean(1 / (self.u_a ** 2) * x_norm + 1 / x_norm)
 
 
+class VPLArcFace(_HeadBase):
+    """criterion.py:619-752; parameter `weight` [C, D]; buffers `mem` [C, D], `life` [C] (the class memory) and the
+    four ArcFace constants upstream registers as buffers (:664-667)."""
+    kind = ops.VPL
+
+    def __init__(self, feat_dim, num_class, s=64.0, m=0.50, easy_margin=True, lamda=0.15, delta=100, device_id=None):
+        super().__init__()
+        _no_model_parallel(device_id)
+        self.feat_dim, self.num_class, self.num_classes = feat_dim, num_class, num_class
+        self.s, self.m, self.easy_margin, self.lamda, self.delta, self.device_id = s, m, easy_margin, lamda, delta, None
+        self.frx_p = (lamda, float(delta))
+        self.weight = nn.Parameter(torch.empty(num_class, feat_dim))
+        nn.init.xavier_uniform_(self.weight)
+        self.register_buffer('mem', torch.zeros(num_class, feat_dim))
+        self.register_buffer('life', torch.zeros(num_class))
+        self.register_buffer('cos_m', torch.tensor(math.cos(m), dtype=torch.float32))
+        self.register_buffer('sin_m', torch.tensor(math.sin(m), dtype=torch.float32))
+        self.register_buffer('th', torch.tensor(math.cos(math.pi - m), dtype=torch.float32))
+        self.register_buffer('mm', torch.tensor(math.sin(math.pi - m) * m, dtype=torch.float32))
+        self.norm_training_flag = True
+
+    @property
+    def frx_flags(self):
+        return int(bool(self.easy_margin)) | (2 if self.norm_training_flag else 0)
+
+    def change_training_mode(self, flag):
+        self.norm_training_flag = flag
+
+    def get_proxy(self, labels):
+        return self.weight.t()[:, labels].clone().detach()      # [D, N] (upstream :684 indexes the wrong axis)
+
+
 class _StandaloneHead(torch.autograd.Function):
     """head(feats, labels) outside a *Net (feature tensors from anywhere)."""
 
@@ -233,9 +265,14 @@ class _StandaloneHead(torch.autograd.Function):
             t = torch.cat([head.batch_mean.view(1), head.batch_std.view(1)]).float().to(feats.device)
         elif kind in (ops.ELASTIC_ARC, ops.ELASTIC_COS):
             t = torch.empty(N, device=feats.device).normal_(head.m, head.std).clamp_(head.m - head.std, head.m + head.std)
+        elif kind == ops.VPL:
+            t = torch.cat([head.mem.reshape(-1), head.life.reshape(-1)]).float().to(feats.device)
         out = ops.head_forward(ctx, x, w.detach().contiguous(), labels.contiguous(), state_t=t, lamb=lamb, want_logits=True)
         if kind == ops.ADA:
             head.batch_mean, head.batch_std = t[0:1].clone(), t[1:2].clone()
+        elif kind == ops.VPL:
+            cd = head.num_classes * D
+            head.mem, head.life = t[:cd].view(head.num_classes, D), t[cd:]
         is_mag = kind == ops.MAG
         logits, loss_g = _StandaloneHead.apply(feats, w, out["logits"], out["loss_g"][0] if is_mag else None, ctx, x,
                                                labels.contiguous(), t)
@@ -316,3 +353,12 @@ class MagFaceNet(_net("magface", ops.MAG, "magface",
                       lambda c: MagFace(FEATURE_DIM, c, s=S_mag, easy_margin=EASY_MARGIN_mag, l_margin=L_MARGIN_mag,
                                         u_margin=U_MARGIN_mag, l_a=L_A_mag, u_a=U_A_mag))):
     """criterion.py:1303-1329"""
+
+
+class VPLArcFaceNet(_net("vpl_arcface", ops.VPL, "vpl_head",
+                         lambda c: VPLArcFace(FEATURE_DIM, c, s=S_vpl, m=M_vpl, easy_margin=EASY_MARGIN_vpl, lamda=LAMDA_vpl,
+                                              delta=DELTA_vpl))):
+    """criterion.py:764-793"""
+
+    def change_training_mode(self, flag):
+        self.vpl_head.change_training_mode(flag)

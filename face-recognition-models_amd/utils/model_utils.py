@@ -213,6 +213,7 @@ def train_model(model, train_loader, criterion, optimizer, scaler, device, epoch
             # whole step inside the engine: no [N,C] logits, no per-step host sync
             eng = model._engine_for(n, images.device)
             model._resync_if_touched()
+            model._sync_head_flags(eng)
             optimizer._apply_pending(eng)
             if eng.kind == ops.SPHERE:
                 eng.sphere_iter = model.head.iter

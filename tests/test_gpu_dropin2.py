@@ -16,7 +16,7 @@ from test_gpu_dropin import DEV, _batch, _mk
 pytestmark = pytest.mark.gpu
 NETS = [("MV_SoftmaxNet", H.MV_AM, "mv_head.weight"), ("AdaFaceNet", H.ADA, "adaface.kernel"),
         ("ElasticArcFaceNet", H.ELASTIC_ARC, "head.kernel"), ("ElasticCosFaceNet", H.ELASTIC_COS, "head.kernel"),
-        ("MagFaceNet", H.MAG, "magface.kernel")]
+        ("MagFaceNet", H.MAG, "magface.kernel"), ("VPLArcFaceNet", H.VPL, "vpl_head.weight")]
 LAMBDA_G = 35.0
 
 
@@ -65,7 +65,7 @@ def test_forward_contract_and_autograd_path_vs_oracle(cls, kind, pname):
     assert (logits.detach().cpu() - rl.detach()).abs().max().item() < 5e-3
     assert (cos_s.cpu() - rc.detach()).abs().max().item() < 5e-3
     if kind == H.MAG:
-        assert loss_g.detach().item() == pytest.approx(float(ref.head.loss_g), rel=1e-4)
+        assert loss_g.detach().item() == pytest.approx(float(ref.head.loss_g.detach()), rel=1e-4)
         rn = rf.detach().norm(dim=1).clamp(10.0, 110.0)
         assert torch.allclose(norms.view(-1).cpu(), rn, rtol=1e-3)  # the CLAMPED norms (criterion.py:1291)
     if kind == H.ADA:
@@ -76,6 +76,24 @@ def test_forward_contract_and_autograd_path_vs_oracle(cls, kind, pname):
     assert (g.cpu() - rg).norm().item() < 0.05 * rg.norm().item()
     hg, rhg = m.head._param().grad, ref.head.weight.grad
     assert (hg.cpu() - rhg).norm().item() < 0.02 * rhg.norm().item()
+    if kind == H.VPL:
+        # the class memory carries over: a second batch sees the first batch's classes as live non-target proxies
+        assert {"vpl_head.mem", "vpl_head.life", "vpl_head.cos_m", "vpl_head.th"} <= set(m.state_dict())
+        assert (m.head.life > 0).sum().item() == len(set(y.tolist()))
+        x2, y2 = _batch(N, C, 4)
+        (c2, l2), _, _, _ = m(x2, y2)
+        (rc2, rl2), _ = ref(x2.cpu(), y2.cpu())
+        assert (l2.detach().cpu() - rl2.detach()).abs().max().item() < 5e-3
+        assert torch.allclose(m.head.life.cpu(), ref.head.state.life)
+        assert (m.head.mem.cpu() - ref.head.state.mem).abs().max().item() < 1e-3 * ref.head.state.mem.abs().max().item()
+        # memory switched off (change_training_mode(False), criterion.py:676): plain ArcFace-style logits, memory untouched
+        m.change_training_mode(False)
+        ref.head.hyper.memory_on = False
+        life_before = m.head.life.clone()
+        (c3, l3), _, _, _ = m(x2, y2)
+        (rc3, rl3), _ = ref(x2.cpu(), y2.cpu())
+        assert (l3.detach().cpu() - rl3.detach()).abs().max().item() < 5e-3
+        assert torch.equal(life_before, m.head.life)
 
 
 def test_magface_fused_train_model_uses_lambda_g():
@@ -99,7 +117,7 @@ def test_magface_fused_train_model_uses_lambda_g():
     assert (w1 - w2).norm().item() < 1e-3 * w1.norm().item()
 
 
-@pytest.mark.parametrize("head", ["mv_arc", "adaface", "elastic_arc", "magface"])
+@pytest.mark.parametrize("head", ["mv_arc", "adaface", "elastic_arc", "magface", "vpl_arcface"])
 def test_engine_bf16_fused_steps_run(head):
     """bf16 speed mode: fused steps stay finite, move the weights, refresh the elastic margins / AdaFace statistics.
     (Gradient parity is pinned above; on a 16-image batch the margin losses first rise for every head, ArcFace included.)"""
@@ -113,5 +131,5 @@ def test_engine_bf16_fused_steps_run(head):
         if head == "magface":
             assert 2 / 110.0 <= out["loss_g"].item() < 1.0
     assert not torch.equal(w0, eng.head_w())
-    if head in ("elastic_arc", "adaface"):
+    if head in ("elastic_arc", "adaface", "vpl_arcface"):
         assert not torch.equal(st0, eng.t)
