@@ -133,3 +133,28 @@ def test_engine_bf16_fused_steps_run(head):
     assert not torch.equal(w0, eng.head_w())
     if head in ("elastic_arc", "adaface", "vpl_arcface"):
         assert not torch.equal(st0, eng.t)
+
+
+def test_elastic_margins_are_redrawn_on_every_graph_replay():
+    """The elastic heads draw their margins inside the captured step (criterion.py:1002 draws them inside forward): every
+    replay of the hipGraph must see fresh ones (torch's graph-safe Philox offsets), not the capture-time draw."""
+    from frx import engine as E
+    eng = E.FaceEngine("elastic_arc", 64, 16, dtype=E.BF16, device=DEV, seed=0)
+    x, y = _batch(16, 64, 1)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        eng.train_step(x, y, 0.002)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = eng.train_step(x, y, 0.002)
+    seen = []
+    for _ in range(3):
+        g.replay()
+        torch.cuda.synchronize()
+        m = eng.t.clone()
+        assert (m - 0.5).abs().max().item() <= 0.0125 + 1e-6 and np.isfinite(out["loss"].item())
+        seen.append(m)
+    assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])

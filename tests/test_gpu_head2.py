@@ -148,3 +148,58 @@ def test_state_is_required():
         ops.head_forward(ctx, x, w, y, state_t=None)
     with pytest.raises(FrxError):
         ops.HeadContext(H.MAG, 8, 64, 10, 64.0, 0.0, device=dev, p=(0.45, 0.8, 110.0, 10.0))   # l_a > u_a
+
+
+@pytest.mark.parametrize("name", ["mv_arc", "adaface", "elastic_arc", "magface", "vpl_arcface"])
+def test_head_full_size_properties(name):
+    """BASELINE head size (N=256, C=10575, D=512): size-independent properties instead of an O(N*C*D) oracle run --
+    lse is the log-sum-exp of the returned logits, loss == mean(lse - z_y), non-target logits are s*cos except where the
+    head re-weights them (MV / VPL), sampled cosines equal a float64 dot product, top-k equals torch.topk, gradients
+    finite; for the scale-invariant heads dx is orthogonal to x."""
+    from frx import ops
+    kind = CASES[name]
+    N, D, Cc = 256, 512, 10575
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(5)
+    hy = H.HeadHyper.default(kind)
+    wshape = (Cc, D) if H.weight_is_cd(kind) else (D, Cc)
+    w = torch.randn(*wshape, generator=g) * 0.05
+    x = torch.randn(N, D, generator=g)
+    y = torch.randint(0, Cc, (N,), generator=g)
+    p, flags = kind_params(kind, hy)
+    ctx = ops.HeadContext(kind, N, D, Cc, hy.s, float(hy.m), device=dev, p=p, flags=flags, lambda_g=0.0)
+    st = None
+    if kind == H.ADA:
+        st = torch.tensor([20.0, 100.0], device=dev)
+    elif kind == H.ELASTIC_ARC:
+        st = torch.empty(N, device=dev).normal_(hy.m, 0.0125).clamp_(hy.m - 0.0125, hy.m + 0.0125)
+    elif kind == H.VPL:
+        st = torch.zeros(Cc * D + Cc, device=dev)
+    xd, wd, yd = x.to(dev), w.to(dev), y.to(dev)
+    o = ops.head_forward(ctx, xd, wd, yd, state_t=st, want_logits=True)
+    z = o["logits"].double().cpu()
+    lse = torch.logsumexp(z, dim=1)
+    np.testing.assert_allclose(o["lse"].cpu().numpy(), lse.numpy(), atol=1e-3)
+    assert abs(o["loss"].item() - (lse - z[torch.arange(N), y]).mean().item()) < 1e-3
+    cs = o["cos_s"].cpu()
+    if kind not in (H.MV_ARC, H.VPL):
+        nt = torch.ones(N, Cc, dtype=torch.bool)
+        nt[torch.arange(N), y] = False
+        assert (o["logits"].cpu()[nt] - cs[nt]).abs().max().item() < 1e-3
+    if kind != H.VPL:           # (VPL's pre-margin cosine is the memory blend, not the plain dot product)
+        wc = (w if H.weight_is_cd(kind) else w.t()).double()
+        xn = torch.nn.functional.normalize(x.double(), dim=1)
+        idx = torch.randint(0, Cc, (64,), generator=g)
+        cos = xn @ torch.nn.functional.normalize(wc[idx], dim=1).t()
+        np.testing.assert_allclose((cs.double()[:, idx] / hy.s).numpy(), cos.clamp(-1, 1).numpy(), atol=1e-3 / 32)
+    _, pred = cs.topk(5, 1, True, True)
+    hit = pred.eq(y.view(-1, 1))
+    assert int(hit[:, :1].sum()) == int(o["topk"][0]) and int(hit.sum()) == int(o["topk"][1])
+    dx, dw = ops.head_backward(ctx, xd, wd, yd, state_t=st)
+    assert torch.isfinite(dx).all() and torch.isfinite(dw).all() and dx.abs().max().item() > 0
+    if kind in (H.MV_ARC, H.ELASTIC_ARC, H.VPL):      # scale-invariant in x: d/ds L(s*x) = 0
+        rad = (dx.cpu() * x).sum(1).abs().max().item()
+        assert rad < 1e-4 * dx.abs().max().item() * x.norm(dim=1).max().item() + 1e-6
+    if kind == H.VPL:
+        life = st[Cc * D:].cpu()
+        assert int((life > 0).sum()) == len(set(y.tolist())) and float(life.max()) == hy.delta - 1
