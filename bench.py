@@ -100,11 +100,14 @@ def kernel_pass(eng, images, labels, steps=3):
 def main():
     # Everything except the final JSON line goes to stderr -- including what native libraries (RCCL prints a
     # version banner at init) write to file descriptor 1.
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(sys.argv[1:], args.gpus))      # (rank 0 of the children prints the JSON line)
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
     try:
-        result = run()
+        result = run(args)
     finally:
         sys.stdout.flush()
         os.dup2(real_stdout, 1)
@@ -113,7 +116,23 @@ def main():
         print(json.dumps(result), flush=True)
 
 
-def run():
+def self_launch(args_list, gpus):
+    """`python bench.py --gpus N` with N > 1 and no launcher: start the N ranks as children of a
+    torch.distributed.run child process BEFORE this process touches the GPU (it never does), pass the
+    child's output through and exit with its code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + args_list
+    log("launching " + " ".join(cmd))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    return subprocess.run(cmd, env=env).returncode
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
@@ -127,15 +146,18 @@ def run():
     ap.add_argument("--lr", type=float, default=0.005)
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--split", action="store_true",
-                    help="run the data-parallel step structure (3 graphs + async all-reduce) even on one GPU")
+                    help="run the data-parallel step structure (graph segments + RCCL all-reduces between them) on one GPU")
+    ap.add_argument("--bf16-buckets", action="store_true", help="data parallel: gradients travel as bf16")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
+    return ap.parse_args()
 
+
+def run(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local_rank)
@@ -148,9 +170,7 @@ def run():
 
     from frx import ddp, engine as E, ops
     dt = ops.BF16 if args.dtype == "bf16" else ops.F32
-    eng = E.FaceEngine(args.head, args.classes, args.batch, dtype=dt, device=dev, seed=0, lambda_g=args.lambda_g)   # same init on all ranks
-    if world > 1:
-        eng.world = world            # grad_scale 1/world in the fused SGD; the all-reduce is issued by the step below
+    eng = E.FaceEngine(args.head, args.classes, args.batch, dtype=dt, device=dev, seed=0, lambda_g=args.lambda_g)
     g = torch.Generator().manual_seed(1234 + rank)
     nb = 4
     batches = [((torch.rand(args.batch, 3, 112, 112, generator=g) * 2 - 1).to(dev),
@@ -160,78 +180,27 @@ def run():
     # The reference's default lr 0.1 (model_utils.py:480) assumes ImageNet-pretrained weights; from the random init
     # used here (and random labels) it diverges to NaN within ~20 steps, and 0.02 still does after a few hundred:
     # the benchmark trains at 0.005, where the loss falls monotonically over 300 steps.
-    eng.net.lr_dev.fill_(args.lr)
 
     def feed(i):
         images.copy_(batches[i % nb][0])
         labels.copy_(batches[i % nb][1])
 
+    # The step driver is the product's own (frx/ddp.py, also behind utils.model_utils.train_model): one hipGraph
+    # on one GPU; graph segments with the gradient all-reduces between them when data parallel.  Rank 0's
+    # parameters are broadcast at construction.
+    stepper = ddp.DataParallelStep(eng, use_graph=not args.no_graph, bf16_buckets=args.bf16_buckets,
+                                   static_inputs=(images, labels), split=args.split)
     log(f"engine ready: {eng.net.n_params} parameters, batch {args.batch}, world {world}")
-    ddp_mode = world > 1 or args.split
-    use_graph = not args.no_graph
+
+    def step(i):
+        feed(i)
+        return stepper.step(None, None, args.lr)
+
     graph = None
-    side = torch.cuda.Stream()
-
-    def capture(fn):
-        """warm up on a side stream, then capture fn into a hipGraph"""
-        side.wait_stream(torch.cuda.current_stream())      # the warm-up must see the initialisation / feed() queued so far
-        with torch.cuda.stream(side):
-            fn()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        g_ = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g_):
-            r = fn()
-        return g_, r
-
-    if ddp_mode:
-        # step = [graph: zero, forward, CE, head + layer4/3 backward] -> async all-reduce of the upper gradient
-        # ranges (overlaps) -> [graph: layer2/1/stem backward] -> all-reduce of the rest -> [graph: SGD + weight prep]
-        rng = eng.net.grad_ranges()
-        grads = eng.net.grads
-        feed(0)
-        if use_graph:
-            eng.step_upper(images, labels); eng.step_lower(); eng.step_update()      # allocate / warm every path once
-            g_up, out = capture(lambda: eng.step_upper(images, labels))
-            g_lo, _ = capture(eng.step_lower)
-            g_sgd, _ = capture(eng.step_update)
-            graph = g_up
-
-        def step(i):
-            feed(i)
-            o_ = out
-            if use_graph:
-                g_up.replay()
-            else:
-                o_ = eng.step_upper(images, labels)
-            works = [dist.all_reduce(grads[lo:hi], async_op=True) for lo, hi in rng["upper"]]
-            if use_graph:
-                g_lo.replay()
-            else:
-                eng.step_lower()
-            works += [dist.all_reduce(grads[lo:hi], async_op=True) for lo, hi in rng["lower"]]
-            for w_ in works:
-                w_.wait()
-            if use_graph:
-                g_sgd.replay()
-            else:
-                eng.step_update()
-            return o_
-    else:
-        if use_graph:
-            feed(0)
-            graph, out = capture(lambda: eng.train_step(images, labels))
-
-        def step(i):
-            feed(i)
-            if graph is not None:
-                graph.replay()
-                return out
-            return eng.train_step(images, labels)
-
-    log("graph captured" if graph is not None else "eager mode")
-    for i in range(args.warmup):
+    for i in range(max(args.warmup, 2)):           # (step 0 is eager, the graphs are captured before step 1)
         step(i)
+    graph = stepper.graphed
+    log(f"{len(stepper.segments())} graph segment(s) captured" if graph else "eager mode")
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -266,12 +235,15 @@ def run():
             intensity, ridge = flops / nbytes, peak * 1e12 / (PEAK_HBM_GBS * 1e9)
             # HBM bytes per launch of that kernel from the PMC passes of scripts/collect_traffic.sh (rocprofv3 cannot
             # run inside this process); null until such a summary has been committed under profiles/
-            traffic = None
+            traffic = traffic_source = None
             tf = os.path.join(ROOT, "profiles", "traffic_latest.json")
             if os.path.exists(tf):
                 with open(tf) as fh:
-                    traffic = json.load(fh).get(label, {}).get("hbm_bytes_per_launch")
-            common = {"kernel": label, "traffic": traffic, "avg_launch_us": round(secs / launches * 1e6, 2),
+                    tj = json.load(fh)
+                traffic = tj.get(label, {}).get("hbm_bytes_per_launch")
+                if traffic is not None:        # where the number comes from: it is NOT measured by this run
+                    traffic_source = {"file": "profiles/traffic_latest.json", **tj.get("_meta", {"collected": "round 1 (r01_f)"})}
+            common = {"kernel": label, "traffic": traffic, "traffic_source": traffic_source, "avg_launch_us": round(secs / launches * 1e6, 2),
                       "launches_per_step": launches // 3, "flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": round(ridge, 1),
                       "mfma_tflops": round(ach_tf, 2), "mfma_frac": round(ach_tf / peak, 4),
                       "hbm_gbs": round(ach_gbs, 1), "hbm_frac": round(ach_gbs / PEAK_HBM_GBS, 4),
@@ -298,7 +270,8 @@ def run():
                                    f"bs={args.batch}/GPU, 112x112, fwd+CE+bwd+SGD(momentum 0.9, wd 5e-4), "
                                    f"random-init weights, BASELINE configs[1]",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
-                       "hip_graph": bool(graph is not None), "lr": args.lr, "final_loss": round(loss, 4)},
+                       "hip_graph": bool(graph), "graph_segments": len(stepper.segments()) if graph else 0,
+                       "bf16_grad_buckets": bool(stepper.bf16), "lr": args.lr, "final_loss": round(loss, 4)},
             "step_mfma_frac": round(ips * flop_img / (world * PEAK_BF16_TFLOPS * 1e12), 4),
             "roofline": roof, "cpu_baseline": cpu,
         }

@@ -4,6 +4,7 @@
 // (main_code/utils/criterion.py:320, model_utils.py:177,185).
 #include "conv_launch.h"
 #include <stdlib.h>
+#include <string.h>
 #include <vector>
 
 namespace frx {
@@ -268,17 +269,22 @@ extern "C" int64_t frx_wgrad_group_bytes(const frx_wgrad_job* jobs, int njobs) {
   return (int64_t)group_items_offset(njobs) + (int64_t)n * (int64_t)sizeof(WgradItem);
 }
 
-extern "C" int frx_wgrad_group_plan(int device, const frx_wgrad_job* jobs, int njobs, void* table_dev, int64_t table_bytes,
-                                    int* nitems) {
-  FRX_CHECK_ARG(table_dev && nitems, "wgrad_group_plan: NULL pointer");
+extern "C" int frx_wgrad_group_plan(int device, frx_stream_t stream, const frx_wgrad_job* jobs, int njobs, void* table_host,
+                                    void* table_dev, int64_t table_bytes, int* nitems) {
+  FRX_CHECK_ARG(table_host && table_dev && nitems, "wgrad_group_plan: NULL pointer");
   std::vector<WgradArgs> layers; std::vector<WgradItem> items;
   const int n = group_build(jobs, njobs, &layers, &items);
   if (n < 0) return n;
   const size_t off = group_items_offset(njobs), need = off + items.size() * sizeof(WgradItem);
   FRX_CHECK_ARG((size_t)table_bytes >= need, "wgrad_group_plan: table needs %zu bytes, got %ld", need, (long)table_bytes);
   FRX_ENTER(device);
-  FRX_HIP(hipMemcpy(table_dev, layers.data(), layers.size() * sizeof(WgradArgs), hipMemcpyHostToDevice));
-  FRX_HIP(hipMemcpy((char*)table_dev + off, items.data(), items.size() * sizeof(WgradItem), hipMemcpyHostToDevice));
+  // host image first, then ONE stream-ordered copy: nothing here synchronises, and the copy is ordered against whatever
+  // the caller's stream did to table_dev before (round 1 used a blocking hipMemcpy, which raced torch's non-blocking
+  // streams: an earlier zero-fill of the table could land after it)
+  memset(table_host, 0, need);
+  memcpy(table_host, layers.data(), layers.size() * sizeof(WgradArgs));
+  memcpy((char*)table_host + off, items.data(), items.size() * sizeof(WgradItem));
+  FRX_HIP(hipMemcpyAsync(table_dev, table_host, need, hipMemcpyHostToDevice, (hipStream_t)stream));
   *nitems = (int)items.size();
   return FRX_OK;
 }

@@ -380,15 +380,25 @@ __device__ __forceinline__ void head_z(float cc, bool target, const HeadConst& h
   }
 }
 
+// A label outside [0, C) (a class-count mismatch between the dataset folders and num_classes) must not become an
+// out-of-bounds access: every kernel indexes with the label clamped into range, and the row's loss is poisoned with
+// NaN so the mistake shows at the caller's next loss read (the reference's CrossEntropyLoss raises there).
+__device__ __forceinline__ int safe_label(int64_t y, int C, bool& bad) {
+  bad = y < 0 || y >= (int64_t)C;
+  return bad ? 0 : (int)y;
+}
+
 // target cosine per row (clamped as the head clamps), and its sum over the batch
 template <int KIND>
-__global__ __launch_bounds__(256) void k_head_ty(const float* __restrict__ cbuf, int N, long ldc,
+__global__ __launch_bounds__(256) void k_head_ty(const float* __restrict__ cbuf, int N, long ldc, int C,
                                                  const int64_t* __restrict__ labels,
                                                  float* __restrict__ ty, float* __restrict__ ty_sum) {
   __shared__ float sh[4];
   float part = 0.f;
   for (int n = threadIdx.x; n < N; n += 256) {
-    const float v = head_clamp<KIND>(cbuf[(long)n * ldc + labels[n]]);
+    bool bad;
+    const int y = safe_label(labels[n], C, bad);
+    const float v = bad ? NAN : head_clamp<KIND>(cbuf[(long)n * ldc + y]);
     ty[n] = v;
     part += v;
   }
@@ -471,11 +481,12 @@ __global__ __launch_bounds__(256) void k_head_rowparam(HeadConst h, const float*
 // mem[cls] = mean of the RAW features of the batch rows labelled cls, life[cls] = delta.  One block per batch row;
 // the first row of each label does the work.
 __global__ __launch_bounds__(256) void k_vpl_mem_update(const float* __restrict__ x, const int64_t* __restrict__ labels,
-                                                        int N, int D, float delta, float* __restrict__ mem,
+                                                        int N, int D, int C, float delta, float* __restrict__ mem,
                                                         float* __restrict__ life) {
   __shared__ int first, cnt;
   const int n = blockIdx.x;
   const int64_t y = labels[n];
+  if (y < 0 || y >= (int64_t)C) return;        // (block-uniform) never WRITE through a bad label; the loss goes NaN
   if (threadIdx.x == 0) { first = N; cnt = 0; }
   __syncthreads();
   for (int i = threadIdx.x; i < N; i += 256)
@@ -544,8 +555,10 @@ __global__ __launch_bounds__(256) void k_head_rows(HeadConst h, const float* __r
                                                    int32_t* __restrict__ rowrank) {
   __shared__ float sh[4];
   __shared__ int shi[4];
+  if (KIND == FRX_SPHERE && (h.flags & 4)) h.lamb = *state_t;
   const int n = blockIdx.x;
-  const int y = (int)labels[n];
+  bool bad_label;
+  const int y = safe_label(labels[n], C, bad_label);
   const float* crow = cbuf + (long)n * ldc;
   const RowCtx r = make_row_ctx(KIND, n, h, xnorm, ty, state_t, rowp);
   const float cy = head_clamp<KIND>(crow[y]);
@@ -598,7 +611,7 @@ __global__ __launch_bounds__(256) void k_head_rows(HeadConst h, const float* __r
   if (threadIdx.x == 0) {
     const float lse = zmax + logf(se);
     if (lse_out) lse_out[n] = lse;
-    rowloss[n] = lse - zy;
+    rowloss[n] = bad_label ? NAN : lse - zy;
     rowrank[n] = shi[0] + shi[1] + shi[2] + shi[3];
   }
 }
@@ -641,8 +654,10 @@ __global__ __launch_bounds__(256) void k_head_grad(HeadConst h, const float* __r
                                                    const float* __restrict__ dlogits,
                                                    float* __restrict__ gbuf, float* __restrict__ dn) {
   __shared__ float sh[4];
+  if (KIND == FRX_SPHERE && (h.flags & 4)) h.lamb = *state_t;
   const int n = blockIdx.x;
-  const int y = (int)labels[n];
+  bool bad_label;
+  const int y = safe_label(labels[n], C, bad_label);
   const float* crow = cbuf + (long)n * Cpad;
   float* grow = gbuf + (long)n * Cpad;
   const RowCtx r = make_row_ctx(KIND, n, h, xnorm, ty, state_t, rowp);
@@ -850,10 +865,12 @@ static bool vpl_memory_on(const frx_head_desc* d) { return d->kind == FRX_VPL &&
 static bool needs_state(int kind) {
   return kind == FRX_CURR || kind == FRX_ADA || kind == FRX_ELASTIC_ARC || kind == FRX_ELASTIC_COS || kind == FRX_VPL;
 }
+static bool needs_state_d(const frx_head_desc* d) { return needs_state(d->kind) || (d->kind == FRX_SPHERE && (d->flags & 4)); }
 static const char* state_what(int kind) {
   return kind == FRX_CURR ? "CurricularFace needs the `t` buffer"
        : kind == FRX_ADA  ? "AdaFace needs its [batch_mean, batch_std] state"
        : kind == FRX_VPL  ? "VPL-ArcFace needs its [mem | life] state"
+       : kind == FRX_SPHERE ? "SphereFace with flags bit 2 reads its lambda from state_t[0]"
                           : "the elastic heads need this step's per-row margins";
 }
 // expands M(KIND) for the runtime kind
@@ -904,7 +921,7 @@ extern "C" int frx_head_fwd_cos(int device, frx_stream_t stream, const frx_head_
   g.C = W.cbuf; g.ldc = W.Cpad; g.row_scale = W.xinv; g.col_scale = W.winv;
   if (int rc = launch_gemm(st, g, 1)) return rc;
   float* tys = ty_sum_out ? ty_sum_out : W.tysum;
-#define FRX_TY(K) hipLaunchKernelGGL(k_head_ty<K>, dim3(1), dim3(256), 0, st, W.cbuf, d->N, (long)W.Cpad, labels, W.ty, tys)
+#define FRX_TY(K) hipLaunchKernelGGL(k_head_ty<K>, dim3(1), dim3(256), 0, st, W.cbuf, d->N, (long)W.Cpad, d->C, labels, W.ty, tys)
   FRX_KIND_SWITCH(d->kind, FRX_TY)
 #undef FRX_TY
   FRX_LAUNCH_CHECK();
@@ -923,7 +940,7 @@ extern "C" int frx_head_vpl_prepare(int device, frx_stream_t stream, const frx_h
   if (ws_bytes < W.bytes) { set_error("head workspace too small: %zu < %zu", ws_bytes, W.bytes); return FRX_ERR_WORKSPACE; }
   float* mem = state_t;
   float* life = state_t + (size_t)d->C * d->D;
-  hipLaunchKernelGGL(k_vpl_mem_update, dim3(d->N), dim3(256), 0, st, x, labels, d->N, d->D, d->p[1], mem, life);
+  hipLaunchKernelGGL(k_vpl_mem_update, dim3(d->N), dim3(256), 0, st, x, labels, d->N, d->D, d->C, d->p[1], mem, life);
   hipLaunchKernelGGL(k_vpl_life_decay, dim3(cdiv(d->C, 256)), dim3(256), 0, st, life, d->C);
   hipLaunchKernelGGL(k_row_norms, dim3(cdiv(d->C, 4)), dim3(256), 0, st, (const float*)mem, d->C, d->D, W.minv, (float*)nullptr);
   FRX_LAUNCH_CHECK();
@@ -934,7 +951,7 @@ extern "C" int frx_head_vpl_prepare(int device, frx_stream_t stream, const frx_h
   if (int rc = launch_gemm(st, g, 1)) return rc;
   hipLaunchKernelGGL(k_vpl_blend, dim3(d->N), dim3(256), 0, st, W.cbuf, (const float*)W.cbuf2, (const float*)life, labels,
                      d->C, (long)W.Cpad, d->p[0]);
-  hipLaunchKernelGGL(k_head_ty<FRX_VPL>, dim3(1), dim3(256), 0, st, W.cbuf, d->N, (long)W.Cpad, labels, W.ty, W.tysum);
+  hipLaunchKernelGGL(k_head_ty<FRX_VPL>, dim3(1), dim3(256), 0, st, W.cbuf, d->N, (long)W.Cpad, d->C, labels, W.ty, W.tysum);
   FRX_LAUNCH_CHECK();
   return FRX_OK;
 }
@@ -945,7 +962,7 @@ extern "C" int frx_head_fwd_loss(int device, frx_stream_t stream, const frx_head
                                  float* norms, float* loss, float* lse, int32_t* topk) {
   if (int rc = check_desc(d)) return rc;
   FRX_CHECK_ARG(labels && ws, "head_fwd_loss: NULL pointer");
-  FRX_CHECK_ARG(!needs_state(d->kind) || state_t, "%s", state_what(d->kind));
+  FRX_CHECK_ARG(!needs_state_d(d) || state_t, "%s", state_what(d->kind));
   FRX_ENTER(device);
   hipStream_t st = (hipStream_t)stream;
   HeadWs W = carve(d, ws);
@@ -1021,7 +1038,7 @@ static int head_bwd_impl(int device, frx_stream_t stream, const frx_head_desc* d
                          float* dw, int accumulate_dw) {
   if (int rc = check_desc(d)) return rc;
   FRX_CHECK_ARG(x && w && labels && ws && dx && dw, "head_bwd: NULL pointer");
-  FRX_CHECK_ARG(!needs_state(d->kind) || state_t, "%s", state_what(d->kind));
+  FRX_CHECK_ARG(!needs_state_d(d) || state_t, "%s", state_what(d->kind));
   FRX_ENTER(device);
   hipStream_t st = (hipStream_t)stream;
   HeadWs W = carve(d, ws);

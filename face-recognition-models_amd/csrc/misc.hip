@@ -220,13 +220,15 @@ extern "C" int frx_weight_prep(int device, frx_stream_t stream, int dtype, int C
 }
 
 extern "C" int frx_input_prep(int device, frx_stream_t stream, int dtype, int N, int H, int W, const void* images,
-                              int is_u8_nhwc, void* out) {
+                              int is_u8_nhwc, void* out, int64_t out_elems) {
   FRX_CHECK_ARG(dtype == FRX_F32 || dtype == FRX_BF16, "input_prep: dtype");
   FRX_CHECK_ARG(images && out && N > 0 && H > 0 && W > 0, "input_prep: bad args");
-  FRX_ENTER(device);
   int hp, wp;
   frx_stem_padded_dims(H, W, &hp, &wp);
   const long total = (long)N * hp * wp;
+  FRX_CHECK_ARG(out_elems == (int64_t)total * 4, "input_prep: a %dx%dx%d batch needs %ld output elements, the destination holds %ld",
+                N, H, W, total * 4, (long)out_elems);
+  FRX_ENTER(device);
   hipStream_t st = (hipStream_t)stream;
   if (is_u8_nhwc) {
     if (dtype == FRX_BF16) hipLaunchKernelGGL(k_input_prep_u8<bf16_t>, dim3(ew_grid2(total)), dim3(256), 0, st, N, H, W, hp, wp, (const uint8_t*)images, (bf16_t*)out);

@@ -65,7 +65,7 @@ _SIGS = {
     "frx_conv_wgrad": (C.c_int, [C.c_int, _P, C.POINTER(ConvDesc), _P, _P, _P, C.c_int, _P, _P]),
     "frx_conv_dgrad_stat_rows": (C.c_int, [C.POINTER(ConvDesc)]),
     "frx_wgrad_group_bytes": (C.c_int64, [C.POINTER(WgradJob), C.c_int]),
-    "frx_wgrad_group_plan": (C.c_int, [C.c_int, C.POINTER(WgradJob), C.c_int, _P, C.c_int64, C.POINTER(C.c_int)]),
+    "frx_wgrad_group_plan": (C.c_int, [C.c_int, _P, C.POINTER(WgradJob), C.c_int, _P, _P, C.c_int64, C.POINTER(C.c_int)]),
     "frx_wgrad_group_run": (C.c_int, [C.c_int, _P, C.c_int, _P, C.c_int, C.c_int]),
     "frx_conv_dgrad_bn": (C.c_int, [C.c_int, _P, C.POINTER(ConvDesc), _P, _P, _P, _P, C.POINTER(DgradFuse)]),
     "frx_conv_wgrad_bn": (C.c_int, [C.c_int, _P, C.POINTER(ConvDesc), _P, _P, _P, C.c_int, _P, _P, _P, _P]),
@@ -87,7 +87,7 @@ _SIGS = {
     "frx_sgd_step": (C.c_int, [C.c_int, _P, C.c_int64, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float]),
     "frx_weight_prep": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "frx_weight_prep_batched": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, _P, _P, C.c_int]),
-    "frx_input_prep": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P]),
+    "frx_input_prep": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int64]),
     "frx_cast": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int64, _P, _P]),
     "frx_colsum_f32": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, _P, _P]),
     "frx_head_bwd_dlogits": (C.c_int, [C.c_int, _P, C.POINTER(HeadDesc), _P, _P, _P, _P, _P, _P, C.c_size_t,

@@ -1,88 +1,190 @@
-"""Data-parallel glue: one process per GPU, gradients all-reduced over RCCL (torch.distributed
-backend "nccl" on ROCm) across xGMI.  The reference has no multi-GPU path at all;
-semantics chosen here:
-  * replicas hold identical weights; each rank owns a shard of the global batch;
-  * one SUM all-reduce of the flat fp32 gradient buffer per step, issued as a few large buckets
-    (xGMI is point-to-point: few large messages), then the fused SGD applies grad_scale = 1/world;
-  * BatchNorm statistics stay per replica (plain-DDP semantics);
-  * CurricularFace's EMA uses the GLOBAL mean target cosine: one extra 1-float all-reduce.
+"""The training step as the product runs it: hipGraph replays on one GPU, and the same stages with
+gradient all-reduces between them on several (one process per GPU, torch.distributed backend "nccl" =
+RCCL over xGMI).  `DataParallelStep` is the ONE step driver: bench.py, utils.model_utils.train_model and
+the multi-process tests all go through it.
+
+The reference has no multi-GPU path at all; semantics chosen here:
+  * replicas hold identical weights (broadcast from rank 0 at attach time); each rank owns a shard of the
+    global batch;
+  * gradients: SUM all-reduce of the flat fp32 gradient buffer in two phases -- the "upper" ranges
+    (head, fc, layer4, layer3: 94 % of the bytes) as soon as their backward is done, overlapping the
+    backward of layer2 / layer1 / stem, then the "lower" rest; few large messages, because xGMI is
+    point-to-point and a ring collective is bound by one link; the fused SGD applies grad_scale = 1/world;
+    optionally the buckets travel as bf16 (half the bytes on the wire, fp32 accumulation in the update);
+  * BatchNorm statistics, AdaFace's norm EMA and VPL's class memory stay per replica (plain-DDP semantics);
+  * CurricularFace's EMA uses the GLOBAL mean target cosine (criterion.py:570-573 on the global batch): one
+    1-float all-reduce between the two head phases, which is why the forward stage ends at the cosines.
+
+A step is four stages of the engine (engine.FaceEngine.stage_*): forward | upper | lower | update.  Consecutive
+stages with no exchange between them are captured into ONE hipGraph: on one GPU the whole step is a single
+graph; data parallel it is (forward+upper) -> (lower) -> (update), or four graphs for CurricularFace.
+
+The engine is duck-typed (tests drive a small CPU model through the very same class over gloo):
+  N, device, world (rw), exchange_ty, ty_sum [1], flat_grads, grad_ranges() -> {"upper": [(lo, hi)..], "lower": [..]},
+  stage_forward(images, labels), stage_upper(labels) -> dict, stage_lower(), stage_update(),
+  set_lr(lr), pre_step(), post_replay(), replica_state() -> [tensors], after_broadcast(), [graph_key()]
 """
 from __future__ import annotations
 
 import torch
 import torch.distributed as dist
 
-
-def bucket_ranges(numel, n_buckets):
-    """Split [0, numel) into n_buckets contiguous 256-element-aligned ranges (last first: the head /
-    fc / layer4 gradients are complete first in backward order)."""
-    n_buckets = max(1, int(n_buckets))
-    step = (numel + n_buckets - 1) // n_buckets
-    step = (step + 255) // 256 * 256
-    out, lo = [], 0
-    while lo < numel:
-        hi = min(numel, lo + step)
-        out.append((lo, hi))
-        lo = hi
-    return out[::-1]
+STAGES = ("forward", "upper", "lower", "update")
 
 
-class GradAllReducer:
-    """Callable(flat_grads): in-place SUM all-reduce across the process group.
-    `via_host` stages through pinned host memory for the gloo backend (CPU rehearsal of the N>1 path)."""
-
-    def __init__(self, group=None, n_buckets=4, via_host=False):
-        self.group, self.n_buckets, self.via_host = group, n_buckets, via_host
-        self.world = dist.get_world_size(group)
-
-    def __call__(self, flat):
-        if self.world == 1:
-            return
-        if self.via_host:
-            h = flat.detach().cpu()
-            dist.all_reduce(h, op=dist.ReduceOp.SUM, group=self.group)
-            flat.copy_(h)
-            return
-        works = [dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-                 for lo, hi in bucket_ranges(flat.numel(), self.n_buckets)]
-        for w in works:
-            w.wait()
+def _world(group):
+    return dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
 
 
-class TargetCosineAllReducer:
-    """Callable(tensor[1]) -> global sample count; sums CurricularFace's sum(t_y) over ranks."""
+def broadcast_parameters(engine, src=0, group=None):
+    """Make every replica start from rank `src`'s parameters, momentum, BN buffers and head state."""
+    if _world(group) == 1:
+        return
+    for t in engine.replica_state():
+        dist.broadcast(t, src, group=group)
+    engine.after_broadcast()
 
-    def __init__(self, local_batch, group=None, via_host=False):
-        self.group, self.via_host = group, via_host
-        self.count = local_batch * dist.get_world_size(group)
 
-    def __call__(self, ty_sum):
-        if self.via_host:
-            h = ty_sum.detach().cpu()
-            dist.all_reduce(h, group=self.group)
-            ty_sum.copy_(h)
+class DataParallelStep:
+    """step(images, labels, lr) -> dict(loss[1], topk[2], ...) of device tensors (valid until the next step)."""
+
+    def __init__(self, engine, group=None, use_graph=True, bf16_buckets=False, broadcast=True, static_inputs=None,
+                 split=False):
+        """static_inputs: optional (images, labels) tensors the caller fills in place before each step(None, None, lr)
+        (bench.py keeps its synthetic batch resident); otherwise step() copies the batch into its own static buffers.
+        split: run the multi-GPU structure (segments + collectives) even in a one-rank group (rehearsal on one GPU)."""
+        self.eng, self.group = engine, group
+        self.world = _world(group)
+        self.multi = self.world > 1 or (bool(split) and dist.is_initialized())
+        engine.world = self.world
+        self.on_gpu = torch.device(engine.device).type == "cuda"
+        self.use_graph = bool(use_graph) and self.on_gpu
+        self.bf16 = bool(bf16_buckets) and self.multi
+        self.images = self.labels = None
+        if static_inputs is not None:
+            self.images, self.labels = static_inputs
+        self._graphs = None            # one hipGraph per segment
+        self._key = None               # engine.graph_key() the graphs were captured under
+        self._warm = False
+        self._out = None
+        self._stage = {}
+        if self.bf16:
+            self._pack = {k: [torch.empty(hi - lo, dtype=torch.bfloat16, device=engine.device) for lo, hi in v]
+                          for k, v in engine.grad_ranges().items()}
+        if broadcast:
+            broadcast_parameters(engine, 0, group)
+
+    # ------------------------------------------------------------------ plan
+    def segments(self):
+        """stage names grouped into graph segments: a segment ends where the host has to issue a collective"""
+        if not self.multi:
+            return [list(STAGES)]
+        segs = [["forward"], ["upper"]] if self.eng.exchange_ty else [["forward", "upper"]]
+        return segs + [["lower"], ["update"]]
+
+    def _run_stage(self, name):
+        e = self.eng
+        if name == "forward":
+            e.stage_forward(self.images, self.labels)
+        elif name == "upper":
+            self._out = e.stage_upper(self.labels)
+        elif name == "lower":
+            e.stage_lower()
         else:
-            dist.all_reduce(ty_sum, group=self.group)
-        return self.count
+            e.stage_update()
 
-
-def attach(engine, group=None, n_buckets=4, via_host=False):
-    """Turn a FaceEngine into one data-parallel replica (weights must already be identical)."""
-    engine.world = dist.get_world_size(group)
-    engine.allreduce = GradAllReducer(group, n_buckets, via_host)
-    from . import ops
-    if engine.kind == ops.CURR:
-        engine.ty_allreduce = TargetCosineAllReducer(engine.N, group, via_host)
-    return engine
-
-
-def broadcast_parameters(engine, src=0, group=None, via_host=False):
-    """Make every replica start from rank `src`'s parameters, momentum and BN buffers."""
-    for t in (engine.net.params, engine.net.mom, engine.net.running_mean, engine.net.running_var, engine.t):
-        if via_host:
-            h = t.detach().cpu()
-            dist.broadcast(h, src, group=group)
-            t.copy_(h)
+    def _run_segment(self, idx, names):
+        if self._graphs is not None:
+            self._graphs[idx].replay()
         else:
-            dist.broadcast(t, src, group=group)
-    engine.net.sync_weights()
+            for n in names:
+                self._run_stage(n)
+
+    # ------------------------------------------------------------------ collectives (host-issued, between segments)
+    def _reduce_ranges(self, which):
+        """start the SUM all-reduce of one set of gradient ranges; returns the handles to finish()"""
+        flat = self.eng.flat_grads
+        handles = []
+        for i, (lo, hi) in enumerate(self.eng.grad_ranges()[which]):
+            if self.bf16:
+                buf = self._pack[which][i]
+                self._cast(flat[lo:hi], buf)
+                handles.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), buf, flat[lo:hi]))
+            else:
+                handles.append((dist.all_reduce(flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True), None, None))
+        return handles
+
+    def _finish(self, handles):
+        for work, buf, dst in handles:
+            work.wait()                 # NCCL: the current stream waits for the collective (no host block)
+            if buf is not None:
+                self._cast(buf, dst)
+
+    def _cast(self, src, dst):
+        if self.on_gpu:
+            from . import ops
+            ops.cast(ops.BF16, src, dst, to_f32=dst.dtype == torch.float32)
+        else:
+            dst.copy_(src)
+
+    # ------------------------------------------------------------------ capture
+    def _engine_key(self):
+        k = getattr(self.eng, "graph_key", None)
+        return k() if k is not None else None
+
+    def _capture(self):
+        graphs = []
+        torch.cuda.synchronize(self.eng.device)
+        for names in self.segments():
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for n in names:
+                    self._run_stage(n)
+            graphs.append(g)
+        self._graphs = graphs
+        self._key = self._engine_key()
+
+    # ------------------------------------------------------------------ the step
+    def step(self, images=None, labels=None, lr=None):
+        e = self.eng
+        if images is not None:
+            if self.images is None:
+                dev = self.eng.device
+                self.images = torch.empty(images.shape, dtype=images.dtype, device=dev)
+                self.labels = torch.empty(labels.shape, dtype=labels.dtype, device=dev)
+            if images.dtype != self.images.dtype or images.shape != self.images.shape:
+                raise ValueError(f"step planned for {tuple(self.images.shape)} {self.images.dtype} batches, "
+                                 f"got {tuple(images.shape)} {images.dtype}")
+            self.images.copy_(images, non_blocking=True)
+            self.labels.copy_(labels, non_blocking=True)
+        if lr is not None:
+            e.set_lr(lr)
+        e.pre_step()
+        # the first step runs eagerly (it is a real step, and it loads every code object); the graphs are captured
+        # -- capturing executes nothing -- right before the second one
+        if self._graphs is not None and self._key != self._engine_key():
+            self._graphs = None        # host-side values baked into the captured launches changed: capture again
+        if self.use_graph and self._graphs is None and self._warm:
+            self._capture()
+        segs = self.segments()
+        pending = []
+        for idx, names in enumerate(segs):
+            self._run_segment(idx, names)
+            if self.multi:
+                last = names[-1]
+                if last == "forward":                   # CurricularFace: global sum of the target cosines
+                    dist.all_reduce(e.ty_sum, op=dist.ReduceOp.SUM, group=self.group)
+                elif last == "upper":
+                    pending += self._reduce_ranges("upper")        # overlaps the lower backward
+                elif last == "lower":
+                    pending += self._reduce_ranges("lower")
+                    self._finish(pending)
+                    pending = []
+        if self._graphs is not None:
+            e.post_replay()
+        self._warm = True
+        return self._out
+
+    @property
+    def graphed(self):
+        return self._graphs is not None

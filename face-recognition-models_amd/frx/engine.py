@@ -201,7 +201,7 @@ class ResNet50Engine:
         if share is None:
             self.reset_parameters()
         if self.grouped_wgrad:
-            self._plan_wgrad_groups()          # here, not at first use: planning synchronises, which a graph capture forbids
+            self._plan_wgrad_groups()          # here, not at first use: the plan's host->device copy must not land inside a graph capture
 
     # ------------------------------------------------------------------ parameter views
     def w_master(self, c: ConvSpec):
@@ -309,8 +309,13 @@ class ResNet50Engine:
     def forward(self, images):
         """images: fp32 NCHW in [-1,1] or uint8 NHWC; returns feats [N,512] fp32 (engine-owned)."""
         N, dt = self.N, self.dtype
-        if images.shape[0] != N:
-            raise ops.FrxError(f"engine was planned for batch {N}, got {images.shape[0]}")
+        if images.dim() != 4 or images.shape[0] != N:
+            raise ops.FrxError(f"engine was planned for batch {N}, got an input of shape {tuple(images.shape)}")
+        hw = tuple(images.shape[1:3]) if images.dtype == torch.uint8 else tuple(images.shape[2:4])
+        if hw != (self.H, self.H):
+            # (the reference's adaptive average pool takes any size; this plan's buffers are sized for one)
+            raise ops.FrxError(f"engine was planned for {self.H}x{self.H} images, got {hw[0]}x{hw[1]}: resize in the "
+                               f"transform (model_utils.py:539-547 feeds 112x112) or build an engine with H={hw[0]}")
         if not self.training:
             # batch statistics of a training step overwrite scale/shift, and running statistics move:
             # rebuild the eval affine whenever weights or statistics changed since it was made
@@ -665,6 +670,7 @@ class FaceEngine:
             self.t = torch.zeros(1, device=self.device) if share is None else share.t
         self.sphere_iter = 0                                 # SphereFace.iter (criterion.py:33): python int
         self.dfeat = torch.zeros(batch, FEATURE_DIM, device=self.device)
+        self.ty_sum = torch.zeros(1, device=self.device)    # sum over the batch of the clamped target cosines (head phase 1)
         self.last = None
         self.world = 1
         self.allreduce = None                                # callable(flat fp32 grads) for data parallel
@@ -733,25 +739,80 @@ class FaceEngine:
                           dx=self.dfeat, dw=self.head_w(self.net.grads), accumulate_dw=False)
         self.net.backward(self.dfeat)
 
-    # the same step in three graph-capturable pieces, so data-parallel training can all-reduce the upper
-    # gradient ranges (94 % of the bytes) while the lower half of the backward still runs
-    def step_upper(self, images, labels):
+    # ------------------------------------------------------------------ the step as graph-capturable stages
+    # (frx/ddp.py: DataParallelStep drives them; consecutive stages with no exchange between them share one hipGraph)
+    #   stage_forward  zero grads, backbone forward, head phase 1 (cosines; sum of target cosines -> self.ty_sum)
+    #   [data parallel, CurricularFace only: all-reduce of ty_sum, criterion.py:570-573 on the global batch]
+    #   stage_upper    head phase 2 (state update, margin, CE, top-k), head backward, backward of fc + layer4 + layer3
+    #   [data parallel: all-reduce of the "upper" gradient ranges starts here and runs under stage_lower]
+    #   stage_lower    backward of layer2, layer1, stem
+    #   [data parallel: all-reduce of the "lower" ranges; wait for both]
+    #   stage_update   fused SGD (grad_scale 1/world, lr from net.lr_dev) + kernel-format weight re-derivation
+    exchange_ty = property(lambda self: self.kind == ops.CURR)
+
+    @property
+    def flat_grads(self):
+        return self.net.grads
+
+    def grad_ranges(self):
+        return self.net.grad_ranges()
+
+    def replica_state(self):
+        """tensors every data-parallel replica must start equal in (broadcast from rank 0)"""
+        return [self.net.params, self.net.mom, self.net.running_mean, self.net.running_var, self.net.num_batches_tracked, self.t]
+
+    def after_broadcast(self):
+        self.net.sync_weights()
+
+    def set_lr(self, lr):
+        if getattr(self, "_lr_host", None) != lr:
+            self.net.lr_dev.fill_(float(lr))
+            self._lr_host = lr
+
+    sgd_momentum, sgd_weight_decay = 0.9, 5e-4      # optim.SGD hyper-parameters of stage_update (model_utils.py:557)
+
+    def graph_key(self):
+        """host-side values a captured launch carries BY VALUE: when one changes the graphs are captured again"""
+        return (self.head.desc.flags & ~4, self.head.desc.lamb if self.kind == ops.MAG else 0.0,
+                self.sgd_momentum, self.sgd_weight_decay, self.world)
+
+    def pre_step(self):
+        """host-side work of a step that stays outside the captured graphs"""
+        self.sample_margins()
+        if self.kind == ops.SPHERE:                  # lambda of this forward goes through the device state (flags bit 2)
+            self.t.fill_(self._lamb())
+
+    def post_replay(self):
+        """a graph replay skips the Python bookkeeping of net.forward() / sync_weights(): redo it"""
+        owner = self.net.share or self.net
+        owner.stats_version = getattr(owner, "stats_version", 0) + 1
+        owner.weights_version = getattr(owner, "weights_version", 0) + 1
+        self.net._eval_affine_ready = False
+
+    def stage_forward(self, images, labels):
         self.net.training = True
         self.net.zero_grad()
-        out = self.forward_loss(images, labels)
+        feats = self.net.forward(images)
+        ops.head_forward_cos(self.head, feats, self.head_w(), labels, state_t=self.t, ty_sum=self.ty_sum)
+
+    def stage_upper(self, labels):
+        out = ops.head_forward_loss(self.head, labels, self.ty_sum, self.N * self.world, state_t=self.t,
+                                    lamb=None if self.kind == ops.SPHERE else 0.0)
+        out["feats"] = self.net.feats
+        self.last = out
         ops.head_backward(self.head, self.net.feats, self.head_w(), labels, state_t=self.t, dx=self.dfeat,
                           dw=self.head_w(self.net.grads), accumulate_dw=False)
         self.net.backward_upper(self.dfeat)
         return out
 
-    def step_lower(self):
+    def stage_lower(self):
         self.net.backward_lower()
 
-    def step_update(self, lr=None):
-        self.net.sgd_step(lr, grad_scale=1.0 / self.world)
+    def stage_update(self):
+        self.net.sgd_step(None, self.sgd_momentum, self.sgd_weight_decay, grad_scale=1.0 / self.world)
 
     def train_step(self, images, labels, lr=None):
-        """zero_grad -> forward -> CE -> backward -> [all-reduce] -> SGD (model_utils.py:176-187)."""
+        """zero_grad -> forward -> CE -> backward -> [all-reduce] -> SGD (model_utils.py:176-187), eagerly."""
         self.net.training = True
         self.net.zero_grad()
         out = self.forward_loss(images, labels)

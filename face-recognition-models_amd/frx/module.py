@@ -21,6 +21,7 @@ import math
 import torch
 import torch.nn as nn
 
+from . import ddp
 from . import engine as E
 from . import ops
 from ._lib import FrxError
@@ -84,6 +85,9 @@ class NativeFaceNet(nn.Module):
         self._primary = None
         self._synced_version = None
         self._last_ctx = None
+        self._steppers = {}           # (batch size, input dtype) -> ddp.DataParallelStep (the fused train step)
+        self._dp = None               # data_parallel() settings
+        self.use_graph = True         # fused train step: replay hipGraphs from the second step of a batch size on
 
     # ------------------------------------------------------------------ engine management
     @property
@@ -109,8 +113,52 @@ class NativeFaceNet(nn.Module):
                            elastic_std=getattr(h, "std", 0.0125))
         if self._primary is None:
             self._adopt(eng)
+            if self._dp is not None:
+                ddp.broadcast_parameters(eng, 0, self._dp["group"])
+        if self._dp is not None:
+            import torch.distributed as dist
+            self._attach_dp(eng, dist.get_world_size(self._dp["group"]))
         self._engines[n] = eng
         return eng
+
+    # ------------------------------------------------------------------ fused step / data parallel
+    def data_parallel(self, group=None, bf16_buckets=False):
+        """Make this model one replica of a data-parallel job (torch.distributed must be initialised, one process per
+        GPU).  Rank 0's parameters are broadcast when the engine is built; the fused train step (train_model with
+        FusedSGD) all-reduces gradients overlapped with the backward (frx/ddp.py); the autograd-compatible path
+        all-reduces after its backward.  The reference has no multi-GPU path."""
+        import torch.distributed as dist
+        self._dp = dict(group=group, bf16_buckets=bool(bf16_buckets))
+        world = dist.get_world_size(group)
+        for eng in self._engines.values():
+            self._attach_dp(eng, world)
+        if self._primary is not None:
+            ddp.broadcast_parameters(self._primary, 0, group)
+        return self
+
+    def _attach_dp(self, eng, world):
+        import torch.distributed as dist
+        group = self._dp["group"]
+        eng.world = world
+
+        def allreduce(flat):
+            dist.all_reduce(flat, group=group)
+
+        def ty_allreduce(t):
+            dist.all_reduce(t, group=group)
+            return eng.N * world
+        eng.allreduce = allreduce if world > 1 else None
+        eng.ty_allreduce = ty_allreduce if (world > 1 and eng.exchange_ty) else None
+
+    def _stepper_for(self, eng, images):
+        key = (eng.N, images.dtype)
+        st = self._steppers.get(key)
+        if st is None:
+            dp = self._dp or {}
+            st = ddp.DataParallelStep(eng, group=dp.get("group"), use_graph=self.use_graph,
+                                      bf16_buckets=dp.get("bf16_buckets", False), broadcast=False)
+            self._steppers[key] = st
+        return st
 
     def _sync_head_flags(self, eng):
         """heads whose flags change at run time (VPL-ArcFace's change_training_mode, criterion.py:676-679)"""
@@ -138,20 +186,21 @@ class NativeFaceNet(nn.Module):
         for i, c in enumerate(net.convs):
             w = net.w_master(c)
             g = net.w_grad(c)
+            mo = net.w_grad(c, net.mom)
             if c.stem:
-                w, g = w[:, :, :7, :3], g[:, :, :7, :3]
+                w, g, mo = w[:, :, :7, :3], g[:, :, :7, :3], mo[:, :, :7, :3]
             m, leaf = sub(c.name + ".weight")
-            self._alias(m, leaf, w.permute(0, 3, 1, 2), g.permute(0, 3, 1, 2))
+            self._alias(m, leaf, w.permute(0, 3, 1, 2), g.permute(0, 3, 1, 2), mo.permute(0, 3, 1, 2))
             m, _ = sub(c.bn + ".weight")
-            self._alias(m, "weight", net.gamma(c), net.gamma(c, net.grads))
-            self._alias(m, "bias", net.beta(c), net.beta(c, net.grads))
+            self._alias(m, "weight", net.gamma(c), net.gamma(c, net.grads), net.gamma(c, net.mom))
+            self._alias(m, "bias", net.beta(c), net.beta(c, net.grads), net.beta(c, net.mom))
             m.running_mean = net._bn(net.running_mean, c)
             m.running_var = net._bn(net.running_var, c)
             m.num_batches_tracked = net.num_batches_tracked[i]
-        self._alias(self.backbone.fc, "weight", net.fc_w(), net.fc_w(net.grads))
-        self._alias(self.backbone.fc, "bias", net.fc_b(), net.fc_b(net.grads))
+        self._alias(self.backbone.fc, "weight", net.fc_w(), net.fc_w(net.grads), net.fc_w(net.mom))
+        self._alias(self.backbone.fc, "bias", net.fc_b(), net.fc_b(net.grads), net.fc_b(net.mom))
         pname = "weight" if hasattr(self.head, "weight") else "kernel"
-        self._alias(self.head, pname, eng.head_w(), eng.head_w(net.grads))
+        self._alias(self.head, pname, eng.head_w(), eng.head_w(net.grads), eng.head_w(net.mom))
         if eng.kind == ops.CURR:
             self.head.t = eng.t
         elif eng.kind == ops.ADA:                      # the two EMA buffers live in the engine's head state
@@ -166,10 +215,11 @@ class NativeFaceNet(nn.Module):
         self._param_list = list(self.parameters())
         self._synced_version = self._version_sum()
 
-    def _alias(self, module, leaf, view, grad_view):
+    def _alias(self, module, leaf, view, grad_view, mom_view):
         p = getattr(module, leaf)
         p.data = view                     # same storage as the engine's flat buffer from now on
         p._frx_grad = grad_view
+        p._frx_mom = mom_view             # the SGD momentum of this parameter, in the parameter's own (torch) shape
 
     def _version_sum(self):
         # a Parameter re-pointed with `.data = view` keeps its OWN version counter, bumped by every

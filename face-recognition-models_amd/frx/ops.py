@@ -91,47 +91,65 @@ class HeadContext:
         return self.desc.N, self.desc.D, self.desc.C
 
 
-def head_forward(ctx: HeadContext, x, w, labels, state_t=None, lamb=0.0, want_logits=False,
-                 ty_allreduce=None):
-    """Returns dict(loss[1], topk[2] int32, norms[N], lse[N], cos_s, logits).
-    ty_allreduce: optional callable(tensor[1]) -> count, summing the target-cosine sum over
-    data-parallel ranks between the two phases (CurricularFace EMA)."""
+def head_forward_cos(ctx: HeadContext, x, w, labels, state_t=None, ty_sum=None):
+    """Phase 1 of the head forward: norms, the cosine GEMM into the workspace, (VPL: class memory + blend) and the
+    per-row target cosines; their batch sum lands in `ty_sum` [1] (the only value a data-parallel CurricularFace has
+    to exchange before phase 2, criterion.py:570-573)."""
     N, D, Cc = ctx.shape
     _chk(x, torch.float32, "x"); _chk(w, torch.float32, "w"); _chk(labels, torch.int64, "labels")
     if tuple(x.shape) != (N, D) or labels.numel() != N or w.numel() != D * Cc:
         raise FrxError(f"head_forward: shapes x{tuple(x.shape)} w{tuple(w.shape)} labels{tuple(labels.shape)} "
                        f"do not match the context (N={N}, D={D}, C={Cc})")
-    if ctx.desc.kind == SPHERE:
-        ctx.desc.lamb = float(lamb)
     dev, st = _dev(x), _stream(x)
-    o = dict(loss=torch.empty(1, device=x.device), topk=torch.empty(2, dtype=torch.int32, device=x.device),
-             norms=torch.empty(N, device=x.device), lse=torch.empty(N, device=x.device),
-             cos_s=None, logits=None)
-    if want_logits:
-        o["cos_s"] = torch.empty(N, Cc, device=x.device)
-        o["logits"] = torch.empty(N, Cc, device=x.device)
+    if ty_sum is None:
+        ty_sum = torch.empty(1, device=x.device)
     L = _lib.lib()
-    if ty_allreduce is None:
-        check(L.frx_head_fwd(dev, st, C.byref(ctx.desc), _p(x), _p(w), _p(labels), _p(state_t), _p(ctx.ws),
-                             ctx.nbytes, _p(o["cos_s"]), _p(o["logits"]), _p(o["norms"]), _p(o["loss"]),
-                             _p(o["lse"]), _p(o["topk"])), "frx_head_fwd")
-    else:
-        tys = torch.empty(1, device=x.device)
-        check(L.frx_head_fwd_cos(dev, st, C.byref(ctx.desc), _p(x), _p(w), _p(labels), _p(ctx.ws), ctx.nbytes,
-                                 _p(tys)), "frx_head_fwd_cos")
-        if ctx.desc.kind == VPL:
-            check(L.frx_head_vpl_prepare(dev, st, C.byref(ctx.desc), _p(x), _p(labels), _p(state_t), _p(ctx.ws), ctx.nbytes),
-                  "frx_head_vpl_prepare")
-        count = ty_allreduce(tys)
-        check(L.frx_head_fwd_loss(dev, st, C.byref(ctx.desc), _p(labels), _p(state_t), _p(tys), int(count),
-                                  _p(ctx.ws), ctx.nbytes, _p(o["cos_s"]), _p(o["logits"]), _p(o["norms"]),
-                                  _p(o["loss"]), _p(o["lse"]), _p(o["topk"])), "frx_head_fwd_loss")
+    check(L.frx_head_fwd_cos(dev, st, C.byref(ctx.desc), _p(x), _p(w), _p(labels), _p(ctx.ws), ctx.nbytes,
+                             _p(ty_sum)), "frx_head_fwd_cos")
+    if ctx.desc.kind == VPL:
+        check(L.frx_head_vpl_prepare(dev, st, C.byref(ctx.desc), _p(x), _p(labels), _p(state_t), _p(ctx.ws), ctx.nbytes),
+              "frx_head_vpl_prepare")
+    return ty_sum
+
+
+def head_forward_loss(ctx: HeadContext, labels, ty_sum, count, state_t=None, lamb=0.0, want_logits=False):
+    """Phase 2: state update from the (global) target-cosine sum over `count` samples, margin + CE + top-k row sweep.
+    Returns dict(loss[1], topk[2] int32, norms[N], lse[N], cos_s, logits[, loss_g, row_param]).
+    SphereFace: lamb=None reads this forward's annealing lambda from state_t[0] (frx_head_desc flags bit 2: a
+    captured graph follows criterion.py:58-60); a number is passed by value."""
+    N, D, Cc = ctx.shape
+    if ctx.desc.kind == SPHERE:
+        if lamb is None:
+            ctx.desc.flags |= 4
+        else:
+            ctx.desc.flags &= ~4
+            ctx.desc.lamb = float(lamb)
+    dev, st = _dev(ty_sum), _stream(ty_sum)
+    device = ty_sum.device
+    o = dict(loss=torch.empty(1, device=device), topk=torch.empty(2, dtype=torch.int32, device=device),
+             norms=torch.empty(N, device=device), lse=torch.empty(N, device=device), cos_s=None, logits=None)
+    if want_logits:
+        o["cos_s"] = torch.empty(N, Cc, device=device)
+        o["logits"] = torch.empty(N, Cc, device=device)
+    L = _lib.lib()
+    check(L.frx_head_fwd_loss(dev, st, C.byref(ctx.desc), _p(labels), _p(state_t), _p(ty_sum), int(count),
+                              _p(ctx.ws), ctx.nbytes, _p(o["cos_s"]), _p(o["logits"]), _p(o["norms"]),
+                              _p(o["loss"]), _p(o["lse"]), _p(o["topk"])), "frx_head_fwd_loss")
     if ctx.desc.kind in (ADA, ELASTIC_ARC, ELASTIC_COS, MAG):
-        o["loss_g"] = torch.empty(1, device=x.device)
-        o["row_param"] = torch.empty(N, device=x.device)
+        o["loss_g"] = torch.empty(1, device=device)
+        o["row_param"] = torch.empty(N, device=device)
         check(L.frx_head_aux(dev, st, C.byref(ctx.desc), _p(state_t), _p(ctx.ws), ctx.nbytes, _p(o["loss_g"]),
                              _p(o["row_param"])), "frx_head_aux")
     return o
+
+
+def head_forward(ctx: HeadContext, x, w, labels, state_t=None, lamb=0.0, want_logits=False,
+                 ty_allreduce=None):
+    """Both phases.  ty_allreduce: optional callable(tensor[1]) -> count, summing the target-cosine sum over
+    data-parallel ranks between them (CurricularFace EMA)."""
+    tys = head_forward_cos(ctx, x, w, labels, state_t)
+    count = ctx.desc.N if ty_allreduce is None else ty_allreduce(tys)
+    return head_forward_loss(ctx, labels, tys, count, state_t, lamb, want_logits)
 
 
 def head_backward(ctx: HeadContext, x, w, labels, state_t=None, gout=None, dx=None, dw=None, accumulate_dw=False):
@@ -267,18 +285,17 @@ def wgrad_group_plan(dtype, jobs):
         raise FrxError("frx_wgrad_group_bytes: " + _lib.lib().frx_last_error().decode())
     dev = jobs[0]["x"].device
     g = WgradGroup()
-    g.table = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
-    # frx_wgrad_group_plan fills the table with a SYNCHRONOUS hipMemcpy, which is not ordered against torch's
-    # non-blocking streams: without this wait the zero-fill above can land after the copy and wipe the table
-    # (seen when the plan ran on a capture warm-up stream: the launch then did nothing, silently).
-    torch.cuda.current_stream(dev).synchronize()
+    g.table = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    # the table is assembled in pinned host memory and copied by one stream-ordered asynchronous copy (enqueue-only,
+    # like every libfrx call); the host image has to outlive that copy, so it stays with the group
+    host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
     n = C.c_int(0)
-    check(_lib.lib().frx_wgrad_group_plan(dev.index or 0, arr, len(jobs), _p(g.table), nbytes, C.byref(n)),
-          "frx_wgrad_group_plan")
+    check(_lib.lib().frx_wgrad_group_plan(_dev(g.table), _stream(g.table), arr, len(jobs), C.c_void_p(host.data_ptr()),
+                                          _p(g.table), nbytes, C.byref(n)), "frx_wgrad_group_plan")
     g.njobs, g.nitems, g.dtype = len(jobs), n.value, dtype
     g.flops = sum(conv_flops(j["d"]) for j in jobs)
     g.nbytes = sum(conv_bytes(j["d"], n_out=2 if j.get("pro_y") is not None else 1, wbytes=j["dw"].numel() * 4) for j in jobs)
-    g.keep = [t for j in jobs for t in j.values() if isinstance(t, torch.Tensor)]
+    g.keep = [t for j in jobs for t in j.values() if isinstance(t, torch.Tensor)] + [host]
     return g
 
 
@@ -398,14 +415,23 @@ def weight_prep_batched(dtype, table, master, total_blocks):
 
 
 def input_prep(dtype, images, out):
+    """images: fp32 [N,3,H,W] in [-1,1] or uint8 [N,H,W,3], contiguous; out: the stem's zero-bordered NHWC4 buffer
+    planned for exactly this N, H, W (the C ABI rejects any other size instead of writing past it)"""
+    if images.dim() != 4:
+        raise FrxError(f"input_prep: expected a 4-d image batch, got shape {tuple(images.shape)}")
     if images.dtype == torch.uint8:
-        N, H, W, _ = images.shape
+        _chk(images, torch.uint8, "images")
+        N, H, W, ch = images.shape
         u8 = 1
     else:
         _chk(images, torch.float32, "images")
-        N, _, H, W = images.shape
+        N, ch, H, W = images.shape
         u8 = 0
-    check(_lib.lib().frx_input_prep(_dev(images), _stream(images), dtype, N, H, W, _p(images), u8, _p(out)), "frx_input_prep")
+    if ch != 3:
+        raise FrxError(f"input_prep: expected 3 colour channels ({'NHWC uint8' if u8 else 'NCHW fp32'}), got shape {tuple(images.shape)}")
+    _chk(out, TORCH_DT[dtype], "input_prep destination")
+    check(_lib.lib().frx_input_prep(_dev(images), _stream(images), dtype, N, H, W, _p(images), u8, _p(out), out.numel()),
+          "frx_input_prep")
     return out
 
 

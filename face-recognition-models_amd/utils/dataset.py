@@ -20,6 +20,14 @@ def default_transform(img):
     return (a / 255.0 - 0.5) / 0.5
 
 
+def uint8_hwc(img):
+    """The image as the decoder left it: uint8 [H, W, 3].  The native train path takes this layout directly -- a quarter
+    of the host->device bytes of the fp32 transform; ToTensor + Normalize(0.5, 0.5) then run on the GPU, fused with the
+    stem's layout change (frx_input_prep), with bit-identical results (tests/test_gpu_conv.py::test_stem)."""
+    import numpy as np
+    return torch.from_numpy(np.asarray(img, dtype=np.uint8).copy())
+
+
 class CASIAwebfaceDataset(Dataset):
     """root_dir/<split>/<identity>/<image>; label = index of the identity folder.  Folders are SORTED
     (upstream uses os.listdir order, which is not reproducible -- SURVEY M9)."""
@@ -27,11 +35,17 @@ class CASIAwebfaceDataset(Dataset):
     def __init__(self, root_dir, split="train", transform=None):
         self.transform = transform or default_transform
         base = os.path.join(root_dir, split)
+        if not os.path.exists(base):
+            raise FileNotFoundError(f"Directory {base} does not exist")
         self.samples = []
-        for label, ident in enumerate(sorted(os.listdir(base))):
+        self.identities = [x for x in sorted(os.listdir(base)) if os.path.isdir(os.path.join(base, x))]
+        self.class_to_idx = {name: i for i, name in enumerate(self.identities)}
+        self.idx_to_class = {i: name for name, i in self.class_to_idx.items()}
+        self.num_of_identities = len(self.identities)
+        for ident, label in self.class_to_idx.items():
             d = os.path.join(base, ident)
-            if os.path.isdir(d):
-                self.samples += [(os.path.join(d, f), label) for f in sorted(os.listdir(d))]
+            self.samples += [(os.path.join(d, f), label) for f in sorted(os.listdir(d))
+                             if f.lower().endswith((".jpg", ".jpeg", ".png"))]
 
     def __len__(self):
         return len(self.samples)

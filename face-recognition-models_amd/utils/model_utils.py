@@ -84,25 +84,44 @@ class FusedSGD(torch.optim.Optimizer):
         eng.net.sgd_step(g["lr"], g["momentum"], g["weight_decay"])
         self.model._synced_version = self.model._version_sum()
 
-    # checkpoints: momentum lives in the engine; expose it in torch.optim.SGD's own format
+    # checkpoints: momentum lives in the engine's flat buffer; it is saved and loaded in torch.optim.SGD's OWN format
+    # (state[i]["momentum_buffer"] per parameter, in the parameter's torch shape), so an optimizer_state_dict written
+    # here resumes upstream's optim.SGD and one written upstream resumes here (model_utils.py:58-65, 126-132)
     def state_dict(self):
         sd = super().state_dict()
-        eng = self.model._primary
-        if eng is not None:
-            sd["frx_momentum"] = eng.net.mom.detach().clone().cpu()
+        if self.model._primary is not None:
+            sd["state"] = {i: {"momentum_buffer": p._frx_mom.detach().clone().contiguous()}
+                           for i, p in enumerate(self.param_groups[0]["params"])}
         return sd
 
     def load_state_dict(self, sd):
         sd = dict(sd)
-        self._pending_mom = sd.pop("frx_momentum", None)
+        legacy = sd.pop("frx_momentum", None)               # round-1 checkpoints: the flat buffer as one blob
+        state = sd.get("state") or {}
+        self._pending_mom = {int(i): st["momentum_buffer"] for i, st in state.items()
+                             if isinstance(st, dict) and st.get("momentum_buffer") is not None}
+        if not self._pending_mom:
+            self._pending_mom = legacy
+        sd["state"] = {}
         super().load_state_dict(sd)
         if self.model._primary is not None:
             self._apply_pending(self.model._primary)
 
     def _apply_pending(self, eng):
-        if self._pending_mom is not None:
-            eng.net.mom.copy_(self._pending_mom.to(eng.device))
-            self._pending_mom = None
+        pend, self._pending_mom = self._pending_mom, None
+        if pend is None:
+            return
+        if isinstance(pend, dict):
+            params = self.param_groups[0]["params"]
+            eng.net.mom.zero_()                             # (parameters without a buffer yet, the stem's padding slots)
+            for i, buf in pend.items():
+                dst = params[i]._frx_mom
+                if tuple(buf.shape) != tuple(dst.shape):
+                    raise ValueError(f"optimizer state: momentum_buffer {i} has shape {tuple(buf.shape)}, "
+                                     f"the parameter has {tuple(dst.shape)}")
+                dst.copy_(buf.to(eng.device, torch.float32))
+        else:
+            eng.net.mom.copy_(pend.to(eng.device))
 
 
 # ---------------------------------------------------------------------------------------------- checkpoints
@@ -166,6 +185,58 @@ def custom_collate_fn(batch):
 _ITERS = {"n": -1}
 
 
+class DevicePrefetcher:
+    """Iterates a loader one batch ahead: batch i+1 travels host -> device on a COPY stream (from pinned memory, so the
+    DMA engine moves it) while the compute stream runs step i.  Works for fp32 CHW batches (the reference's transform,
+    model_utils.py:539-547) and for uint8 HWC batches (dataset.uint8_hwc: a quarter of the PCIe bytes; ToTensor +
+    Normalize then run on the GPU inside frx_input_prep).  Upstream does a pageable synchronous `.to(device)` (:173)."""
+
+    def __init__(self, loader, device):
+        self.loader, self.device = loader, torch.device(device)
+        self.cuda = self.device.type == "cuda"
+        if self.cuda:
+            self.copy_stream = torch.cuda.Stream(self.device)
+
+    def _upload(self, batch):
+        if batch is None or batch[0] is None or not self.cuda:
+            return batch, None
+        with torch.cuda.stream(self.copy_stream):
+            moved = []
+            for t in batch:
+                if isinstance(t, torch.Tensor):
+                    if not t.is_cuda and not t.is_pinned():
+                        t = t.pin_memory()
+                    moved.append(t.to(self.device, non_blocking=True))
+                else:
+                    moved.append(t)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        return tuple(moved), ev
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __iter__(self):
+        it = iter(self.loader)
+        try:
+            nxt = self._upload(next(it))
+        except StopIteration:
+            return
+        while nxt is not None:
+            cur, ev = nxt
+            try:
+                nxt = self._upload(next(it))
+            except StopIteration:
+                nxt = None
+            if ev is not None:
+                main = torch.cuda.current_stream(self.device)
+                main.wait_event(ev)
+                for t in cur:                      # the caching allocator must not recycle the batch while `main` uses it
+                    if isinstance(t, torch.Tensor) and t.is_cuda:
+                        t.record_stream(main)
+            yield cur
+
+
 def _is_plain_ce(criterion):
     return (isinstance(criterion, nn.CrossEntropyLoss) and criterion.weight is None and criterion.reduction == "mean"
             and getattr(criterion, "label_smoothing", 0.0) == 0.0 and criterion.ignore_index == -100)
@@ -177,8 +248,9 @@ def train_model(model, train_loader, criterion, optimizer, scaler, device, epoch
     meters = {k: AverageMeter(n, f) for k, n, f in (
         ("bt", "Time", ":6.3f"), ("dt", "Data", ":6.3f"), ("tp", "ThroughPut", ":.2f"), ("loss", "Loss", ":.3f"),
         ("lid", "L_ID", ":.3f"), ("lmag", "L_mag", ":.6f"), ("a1", "Acc@1", ":6.2f"), ("a5", "Acc@5", ":6.2f"))}
-    progress = ProgressMeter(len(train_loader), [meters["bt"], meters["dt"], meters["tp"], "images/s", meters["loss"],
-                                                 meters["lid"], meters["lmag"], meters["a1"], meters["a5"]],
+    progress = ProgressMeter(len(train_loader) if hasattr(train_loader, "__len__") else 0,
+                             [meters["bt"], meters["dt"], meters["tp"], "images/s", meters["loss"],
+                              meters["lid"], meters["lmag"], meters["a1"], meters["a5"]],
                              prefix=f"Epoch: [{epoch}/{epochs}]")
     # (loss_g is the integer 0 for every head but MagFace, whose fused backward takes lambda_g itself)
     fused = isinstance(model, NativeFaceNet) and isinstance(optimizer, FusedSGD) and _is_plain_ce(criterion)
@@ -200,17 +272,17 @@ def train_model(model, train_loader, criterion, optimizer, scaler, device, epoch
             _ITERS["n"] += 1
         pending.clear()
 
-    for i, batch in enumerate(train_loader):
+    for i, batch in enumerate(DevicePrefetcher(train_loader, device)):
         if batch is None or batch[0] is None:
             continue
         images, target = batch
         meters["dt"].update(time.time() - end)
-        images = images.to(device, non_blocking=True)
-        target = target.to(device, non_blocking=True)
         n = images.size(0)
         lr = optimizer.param_groups[0]["lr"]
         if fused:
-            # whole step inside the engine: no [N,C] logits, no per-step host sync
+            # whole step inside the engine (frx/ddp.py: DataParallelStep): no [N,C] logits, no per-step host sync;
+            # from the second step of a batch size on it is a hipGraph replay (plus the gradient all-reduces
+            # between the graph segments when the model is a data-parallel replica)
             eng = model._engine_for(n, images.device)
             model._resync_if_touched()
             model._sync_head_flags(eng)
@@ -218,7 +290,9 @@ def train_model(model, train_loader, criterion, optimizer, scaler, device, epoch
             if eng.kind == ops.SPHERE:
                 eng.sphere_iter = model.head.iter
             eng.set_lambda_g(lambda_g)
-            out = eng.train_step(images.contiguous(), target.contiguous(), lr)
+            g0 = optimizer.param_groups[0]
+            eng.sgd_momentum, eng.sgd_weight_decay = g0["momentum"], g0["weight_decay"]
+            out = model._stepper_for(eng, images).step(images, target.contiguous(), lr)
             if eng.kind == ops.SPHERE:
                 model.head.iter = eng.sphere_iter
             model._synced_version = model._version_sum()
@@ -376,25 +450,70 @@ def make_optimizer(model, lr):
     return torch.optim.SGD(model.parameters(), lr=lr, momentum=0.9, weight_decay=5e-4)
 
 
+def check_label_range(datasets, num_classes):
+    """Labels index the head's class axis on the device; a dataset with more identity folders than `num_classes`
+    must fail HERE, like upstream's CrossEntropyLoss would on the first such batch (the kernels themselves clamp the
+    index and turn the loss into NaN rather than read out of bounds)."""
+    for ds in datasets:
+        n = getattr(ds, "num_of_identities", None)
+        if n is None and hasattr(ds, "samples") and len(ds.samples):
+            n = 1 + max(int(lbl) for _, lbl in ds.samples)
+        if n is not None and n > num_classes:
+            raise ValueError(f"dataset holds {n} identities but the head was built for num_classes={num_classes}: "
+                             f"labels would fall outside [0, {num_classes})")
+
+
+def init_data_parallel():
+    """One process per GPU (launched by `python -m torch.distributed.run --nproc-per-node N arcface.py ...`): join the
+    RCCL process group.  -> (rank, world, device); (0, 1, default device) when not launched that way.  The reference
+    has no multi-GPU path."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1 or not torch.cuda.is_available():
+        return 0, 1, torch.device("cuda" if torch.cuda.is_available() else "cpu")
+    import torch.distributed as dist
+    rank, local = int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    return rank, world, device
+
+
 def main_pipeline(model_class, model_name, project_name, model_final_filename, model_best_filename, num_classes,
                   working_path, dataset_path):
+    from torch.utils.data.distributed import DistributedSampler
+    from .dataset import uint8_hwc
     t_start = time.time()
     args = parse_args()
-    device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
-    wandb.init(project=project_name, name=model_name, config=vars(args), dir=f"{WORKING_PATH}/wandb")
+    rank, world, device = init_data_parallel()
+    lead = rank == 0
+    if lead:
+        wandb.init(project=project_name, name=model_name, config=vars(args), dir=f"{WORKING_PATH}/wandb")
     ckpt_dir = f"{working_path}/checkpoints/{model_name}"
-    if args.continue_train is None and os.path.exists(ckpt_dir):
+    if lead and args.continue_train is None and os.path.exists(ckpt_dir):
         shutil.rmtree(ckpt_dir)
         print("Training from scratch, reset all checkpoints...")
     os.makedirs(ckpt_dir, exist_ok=True)
-    print(f"Training using {device} - batch size {args.batch_size} - epochs {args.epochs} - learning rate {args.learning_rate}")
-
-    root = f"{dataset_path}/CASIA-WebFace"
-    train_dataset = ConcatDataset([CASIAwebfaceDataset(root, "train"), CASIAwebfaceDataset(root, "valid")])
-    train_loader = DataLoader(train_dataset, batch_size=args.batch_size, shuffle=True, num_workers=8,
-                              collate_fn=custom_collate_fn, pin_memory=True)
+    print(f"Training using {device} - batch size {args.batch_size}{' per GPU x ' + str(world) if world > 1 else ''} - "
+          f"epochs {args.epochs} - learning rate {args.learning_rate}")
 
     model = model_class(num_classes=num_classes, backbone=BACKBONE).to(device)
+    native = isinstance(model, NativeFaceNet) and device.type == "cuda"
+    root = f"{dataset_path}/CASIA-WebFace"
+    # native path: batches stay uint8 HWC until they are on the GPU (a quarter of the PCIe bytes; frx_input_prep applies
+    # ToTensor + Normalize there); otherwise the reference's transform (model_utils.py:539-547)
+    tf = uint8_hwc if native else None
+    parts = [CASIAwebfaceDataset(root, "train", transform=tf), CASIAwebfaceDataset(root, "valid", transform=tf)]
+    check_label_range(parts, num_classes)
+    train_dataset = ConcatDataset(parts)
+    sampler = DistributedSampler(train_dataset, num_replicas=world, rank=rank, shuffle=True) if world > 1 else None
+    train_loader = DataLoader(train_dataset, batch_size=args.batch_size, shuffle=sampler is None, sampler=sampler,
+                              num_workers=8, collate_fn=custom_collate_fn, pin_memory=True, drop_last=world > 1)
+
+    if world > 1 and native:
+        model.data_parallel()
     criterion = nn.CrossEntropyLoss().to(device)
     optimizer = make_optimizer(model, args.learning_rate)
     scheduler = get_scheduler(optimizer, "customstep")
@@ -404,14 +523,22 @@ def main_pipeline(model_class, model_name, project_name, model_final_filename, m
     best = float("inf") if best is None else best
     last = args.epochs + start_epoch - 1
     for epoch in range(start_epoch, last + 1):
+        if sampler is not None:
+            sampler.set_epoch(epoch)
         loss = train_model(model, train_loader, criterion, optimizer, scaler, device, epoch, last, args)
-        if loss < best:
+        if lead and loss < best:
             best = loss
             save_checkpoint(model, optimizer, scheduler, scaler, loss, epoch, ckpt_dir, model_name, isCheckpoint=False)
             print(f"New best model saved: {loss:.6f}")
-        save_checkpoint(model, optimizer, scheduler, scaler, loss, epoch, ckpt_dir, model_name, isCheckpoint=True)
+        if lead:
+            save_checkpoint(model, optimizer, scheduler, scaler, loss, epoch, ckpt_dir, model_name, isCheckpoint=True)
         scheduler.step()
-    torch.save(model.state_dict(), f"{ckpt_dir}/{model_final_filename}")
-    wandb.save(f"{ckpt_dir}/*")
-    wandb.finish()
+    if lead:
+        torch.save(model.state_dict(), f"{ckpt_dir}/{model_final_filename}")
+        wandb.save(f"{ckpt_dir}/*")
+        wandb.finish()
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
     print(f"Code runs in {time.time() - t_start}s")

@@ -75,7 +75,9 @@ typedef struct frx_head_desc {
                         MAG:  p[0] = l_margin, p[1] = u_margin, p[2] = l_a, p[3] = u_a (criterion.py:1188-1191)
                         VPL:  p[0] = lamda, p[1] = delta (criterion.py:632-633) */
   int32_t flags;     /* MAG, VPL: bit 0 = easy_margin (criterion.py:1187, 631)
-                        VPL: bit 1 = norm_training_flag, the memory is in use (criterion.py:671-679) */
+                        VPL: bit 1 = norm_training_flag, the memory is in use (criterion.py:671-679)
+                        SPHERE: bit 2 = read the annealing lambda from state_t[0] instead of `lamb` (a captured
+                                hipGraph then follows criterion.py:58-60 without re-capture) */
   int32_t reserved;
 } frx_head_desc;
 
@@ -85,6 +87,7 @@ typedef struct frx_head_desc {
  *   ELASTIC_*     [N]  this step's per-row margins, already sampled and clamped by the caller
  *                      (torch.normal + clamp, criterion.py:1002-1004 / 1113-1115; read only)
  *   VPL           [C*D + C]  `mem` [C,D] then `life` [C] (criterion.py:660-661), both updated by frx_head_vpl_prepare
+ *   SPHERE        [1]  only with flags bit 2: this forward's annealing lambda (read only)
  *   other kinds   may be NULL */
 
 size_t frx_head_workspace_bytes(const frx_head_desc* d);
@@ -220,8 +223,10 @@ typedef struct frx_wgrad_job {
   float* dw;
 } frx_wgrad_job;
 int64_t frx_wgrad_group_bytes(const frx_wgrad_job* jobs, int njobs);          /* size of the device table; < 0: error */
-int frx_wgrad_group_plan(int device, const frx_wgrad_job* jobs, int njobs, void* table_dev, int64_t table_bytes,
-                         int* nitems);                                        /* synchronous (host -> device copy) */
+/* Enqueue-only like every other call: the table is built in `table_host` (table_bytes of PINNED host memory owned by the
+ * caller, to be kept alive until the copy has run) and copied to `table_dev` by ONE asynchronous copy on `stream`. */
+int frx_wgrad_group_plan(int device, frx_stream_t stream, const frx_wgrad_job* jobs, int njobs, void* table_host,
+                         void* table_dev, int64_t table_bytes, int* nitems);
 int frx_wgrad_group_run(int device, frx_stream_t stream, int dtype, const void* table_dev, int njobs, int nitems);
 
 /* ---------------------------------------------------------------- backbone: BatchNorm / ReLU / residual / pools
@@ -270,7 +275,9 @@ int frx_avgpool_bwd(int device, frx_stream_t stream, int dtype, int N, int HW, i
  *   (model_utils.py:557,186).  lr_dev (optional device scalar) overrides lr, so a captured
  *   hipGraph follows the CustomStepLR schedule (schedulers.py:3-14) without re-capture.
  * frx_input_prep: ToTensor + Normalize(0.5,0.5) (model_utils.py:539-547) fused with the layout
- *   change to the stem's zero-bordered NHWC4; `images` is fp32 NCHW in [-1,1] or uint8 NHWC. */
+ *   change to the stem's zero-bordered NHWC4; `images` is fp32 NCHW in [-1,1] or uint8 NHWC.
+ *   out_elems = element count of `out`; it must equal N*Hp*Wp*4 for this H, W (frx_stem_padded_dims),
+ *   otherwise FRX_ERR_ARG (an image of another size would overrun a buffer planned for 112x112). */
 int frx_sgd_step(int device, frx_stream_t stream, int64_t n, float* p, const float* g, float* buf,
                  const float* lr_dev, float lr, float momentum, float weight_decay, float grad_scale);
 int frx_weight_prep(int device, frx_stream_t stream, int dtype, int Co, int RS, int Ci, const float* master_krsc,
@@ -281,7 +288,7 @@ int frx_weight_prep(int device, frx_stream_t stream, int dtype, int Co, int RS, 
 int frx_weight_prep_batched(int device, frx_stream_t stream, int dtype, int n, const int64_t* table_dev,
                             const float* master, int total_blocks);
 int frx_input_prep(int device, frx_stream_t stream, int dtype, int N, int H, int W, const void* images,
-                   int is_u8_nhwc, void* out);
+                   int is_u8_nhwc, void* out, int64_t out_elems);
 int frx_cast(int device, frx_stream_t stream, int dtype, int to_f32, int64_t n, const void* x, void* y);
 int frx_colsum_f32(int device, frx_stream_t stream, int rows, int C, const float* x, float* out);
 

@@ -58,7 +58,7 @@ def main():
     torch.set_num_threads(4)
 
     # ------------------------------------------------------------------ heads
-    N, D, C = 24, 128, 50
+    N, D, C = 32, 512, 100          # the D the kernels run at (the K loop of the cosine GEMM is 512 deep)
 
     def make_head(kind):
         with contextlib.redirect_stdout(None):

@@ -16,6 +16,7 @@ from oracle.resnet50 import FaceNet
 
 pytestmark = pytest.mark.gpu
 DEV = torch.device("cuda:0")
+LOGIT_TOL = 1e-3          # north-star tolerance on logits / cos_s (cosine x s), whole net in fp32 parity mode
 
 
 def _mk(cls_name, C, dtype="f32", seed=0):
@@ -58,7 +59,7 @@ def test_forward_contract_and_autograd_path_vs_oracle(cls, kind):
     rloss = F.cross_entropy(rl, y.cpu())
     rloss.backward()
     assert abs(loss.item() - rloss.item()) < 1e-3
-    assert (logits.detach().cpu() - rl.detach()).abs().max().item() < 5e-3
+    assert (logits.detach().cpu() - rl.detach()).abs().max().item() < LOGIT_TOL
     g = m.backbone.fc.weight.grad
     assert g is not None and m.backbone.conv1.weight.grad.shape == (64, 3, 7, 7)
     rg = ref.backbone.fc.weight.grad

@@ -12,6 +12,7 @@ from oracle.resnet50 import FaceNet, make_sgd, train_step
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
+LOGIT_TOL = 1e-3          # north-star tolerance on embeddings AND on logits (cosine x 64), whole net, fp32 parity mode
 KINDS = {"arcface": H.ARC, "cosface": H.COS, "sphereface": H.SPHERE, "curricular": H.CURR}
 
 
@@ -68,9 +69,13 @@ def test_train_steps_fp32_vs_oracle(kind):
         fr = F.normalize(feats.detach(), dim=1)
         if step == 0:
             # ---- forward parity (identical weights): north-star 1e-3 on embeddings and logits
-            assert (fe - fr).abs().max().item() < 1e-3
-            assert (out["logits"].cpu() - logits.detach()).abs().max().item() < 1e-3 * 64 * 0 + 5e-3
-            assert (out["cos_s"].cpu() - cos_s.detach()).abs().max().item() < 5e-3
+            e_emb = (fe - fr).abs().max().item()
+            e_logit = (out["logits"].cpu() - logits.detach()).abs().max().item()
+            e_cos = (out["cos_s"].cpu() - cos_s.detach()).abs().max().item()
+            print(f"{kind}: max |d embedding| {e_emb:.2e}, max |d logit| {e_logit:.2e}, max |d cos_s| {e_cos:.2e} (bar {LOGIT_TOL})")
+            assert e_emb < LOGIT_TOL
+            assert e_logit < LOGIT_TOL
+            assert e_cos < LOGIT_TOL
             assert abs(out["loss"].item() - loss.item()) < 1e-3
             # ---- backward parity, judged against float64
             ref64.train()

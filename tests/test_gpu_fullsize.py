@@ -91,11 +91,12 @@ def test_loss_goes_down_on_a_repeated_batch():
 
 
 def test_upper_gradients_are_final_after_the_first_backward_half():
-    """What the overlapped all-reduce relies on: after step_upper() the upper gradient ranges (layer3/4, fc, head: 94 %
+    """What the overlapped all-reduce relies on: after stage_upper() the upper gradient ranges (layer3/4, fc, head: 94 %
     of the bytes) do not change any more, and the lower ranges are still untouched."""
     eng = _engine()
     x, y = _batch(4)
-    eng.step_upper(x, y)
+    eng.stage_forward(x, y)
+    eng.stage_upper(y)
     g1 = eng.net.grads.clone()
     rng = eng.net.grad_ranges()
     for lo, hi in rng["lower"]:
@@ -104,7 +105,7 @@ def test_upper_gradients_are_final_after_the_first_backward_half():
         assert g1[lo:hi].abs().max().item() > 0.0
     up = sum(hi - lo for lo, hi in rng["upper"])
     assert up / eng.net.n_params > 0.9
-    eng.step_lower()
+    eng.stage_lower()
     g2 = eng.net.grads
     for lo, hi in rng["upper"]:
         assert torch.equal(g2[lo:hi], g1[lo:hi])
@@ -142,3 +143,168 @@ def test_graph_replay_stays_finite_unsynchronised():
     for c in eng.net.convs:
         g = eng.net.w_grad(c)
         assert torch.isfinite(g).all() and g.abs().max().item() > 0.0, c.name
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE configs[2] / [3] / [4] at their per-GPU sizes ("configs untested at full size")
+# ------------------------------------------------------------------------------------------------------------------
+def _face_engine(kind, n, c, seed=0):
+    from frx import engine as E, ops
+    return E.FaceEngine(kind, c, n, dtype=ops.BF16, device=DEV, seed=seed)
+
+
+def _face_batch(n, c, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(n, 3, 112, 112, generator=g) * 2 - 1).to(DEV), torch.randint(0, c, (n,), generator=g).to(DEV)
+
+
+def _head_reference_loss(eng, feats, labels, kind):
+    """closed-form CosFace / CurricularFace loss from the engine's own features and weights, in float64 on the GPU"""
+    x = torch.nn.functional.normalize(feats.double(), dim=1)
+    w = torch.nn.functional.normalize(eng.head_w().double(), dim=0)            # `kernel` [512, C]: column norms
+    cos = x @ w
+    rows = torch.arange(feats.shape[0], device=feats.device)
+    if kind == "cosface":
+        cos = cos.clamp(-1 + 1e-4, 1 - 1e-4)
+        z = cos.clone()
+        z[rows, labels] -= eng.m
+        return torch.nn.functional.cross_entropy(z * eng.s, labels).item(), cos
+    return None, cos.clamp(-1, 1)
+
+
+def test_cosface_full_size_step_configs2_per_gpu_shape():
+    """configs[2] per-GPU shape: CosFace R50, 10 575 classes, batch 256, bf16.  Forward bit-reproducible; the head's
+    loss / top-k equal a float64 evaluation of the closed form on the same features within the 1e-3 logit bar; the
+    product's step driver (one captured graph) brings the loss down on a repeated batch with every gradient alive."""
+    from frx import ddp
+    eng = _face_engine("cosface", N, C)
+    x, y = _face_batch(N, C, 11)
+    a = eng.forward_loss(x, y, want_logits=True)
+    f1, l1, lg = a["feats"].clone(), a["loss"].clone(), a["logits"].clone()
+    b = eng.forward_loss(x, y)
+    assert torch.equal(b["feats"], f1) and torch.equal(b["loss"], l1)
+    ref_loss, cos = _head_reference_loss(eng, f1, y, "cosface")
+    assert abs(l1.item() - ref_loss) < 1e-3
+    z = cos.clone(); z[torch.arange(N, device=DEV), y] -= eng.m
+    assert (lg.double() - z * eng.s).abs().max().item() < 1e-3                 # north-star bar on logits, full size
+    top5 = (cos * eng.s).topk(5, dim=1).indices
+    assert int(a["topk"][0]) == int((top5[:, 0] == y).sum()) and int(a["topk"][1]) == int((top5 == y[:, None]).any(1).sum())
+    st = ddp.DataParallelStep(eng)
+    ls = [st.step(x, y, 0.005)["loss"].item() for _ in range(30)]
+    assert st.graphed and all(np.isfinite(ls)) and max(ls[-4:]) < ls[0] - 3.0, ls
+    for c in eng.net.convs:
+        g = eng.net.w_grad(c)
+        assert torch.isfinite(g).all() and g.abs().max().item() > 0.0, c.name
+    hg = eng.head_w(eng.net.grads)
+    assert torch.isfinite(hg).all() and hg.abs().max().item() > 0.0
+
+
+def test_curricularface_85k_whole_step_configs3_per_gpu_shape():
+    """configs[3] per-GPU shape: CurricularFace R50, 85 000 classes, batch 128, bf16 -- the WHOLE step (backbone, the
+    [128, 85 000] head, backward, fused SGD over 68 M parameters) through the step driver: finite, the EMA `t` follows
+    criterion.py:570-573 on the engine's own target cosines, the loss falls on a repeated batch, and the data-parallel
+    segment plan for this head is four graphs (exchange of the target-cosine sum between the head phases)."""
+    from frx import ddp
+    n, c = 128, 85000
+    eng = _face_engine("curricular", n, c)
+    x, y = _face_batch(n, c, 12)
+    st = ddp.DataParallelStep(eng)
+    assert eng.exchange_ty
+    ls, ts = [], []
+    t_expect = 0.0
+    for i in range(12):
+        if i < 3:                                      # the EMA against a float64 restatement on the step's own features
+            eng.net.training = True
+            feats = eng.net.forward(x).clone()
+            eng.net.num_batches_tracked -= 1
+            _, cos = _head_reference_loss(eng, feats, y, "curricular")
+            t_expect = 0.01 * cos[torch.arange(n, device=DEV), y].mean().item() + 0.99 * t_expect
+        out = st.step(x, y, 0.005)
+        ls.append(out["loss"].item()); ts.append(eng.t.item())
+        if i < 3:
+            assert ts[-1] == pytest.approx(t_expect, abs=2e-5), (i, ts[-1], t_expect)
+    assert st.graphed and all(np.isfinite(ls)) and ls[-1] < ls[0] - 1.0, ls
+    assert eng.net.params.abs().max().item() < 50.0
+    hg = eng.head_w(eng.net.grads)
+    assert torch.isfinite(hg).all() and hg.abs().max().item() > 0.0
+    for cv in eng.net.convs:
+        assert eng.net.w_grad(cv).abs().max().item() > 0.0, cv.name
+    st.multi = True
+    assert st.segments() == [["forward"], ["upper"], ["lower"], ["update"]]
+
+
+def test_lfw_6000_pairs_end_to_end_configs4():
+    """configs[4]: 6000 pairs (3000 same / 3000 different) over 12 000 synthetic images with REAL separation -- every
+    identity is a smooth random pattern, each image a noisy rendition of it with a per-image noise level, so the
+    similarity distributions overlap and thresholds matter (random images through random weights give ~50 %).  The
+    product path (embed each image once at B = 512, pair-cosine kernel, device-side threshold counts, 10-fold protocol of
+    model_utils.py:416-474) must equal the CPU oracle's protocol on the same similarities to +-0.2 % accuracy (north
+    star), and a subset of the similarities must equal the CPU oracle NETWORK's (fp32 parity engine) within 1e-3."""
+    import torch.nn.functional as F
+    from oracle import heads as H, verify as OV
+    from oracle.resnet50 import FaceNet
+    from test_gpu_dropin import _mk
+    from utils import model_utils as MU
+    from utils.dataset import FlatPairDataset
+    rng = np.random.RandomState(0)
+    n_id, per_id, P = 3000, 4, 6000                      # 12 000 images
+    coarse = torch.from_numpy(rng.rand(n_id, 3, 7, 7).astype(np.float32) * 2 - 1)
+    base = F.interpolate(coarse, size=(112, 112), mode="bilinear", align_corners=False)
+    gen = torch.Generator().manual_seed(1)
+
+    def render(img_id):
+        ident, k = divmod(int(img_id), per_id)
+        g = torch.Generator().manual_seed(1000003 * ident + k)
+        sigma = 0.1 + 1.4 * torch.rand(1, generator=g).item()
+        return (base[ident] + sigma * torch.randn(3, 112, 112, generator=g)).clamp(-1, 1)
+    same = np.r_[np.ones(P // 2), np.zeros(P // 2)].astype(np.int64)
+    rng.shuffle(same)
+    ida = rng.randint(0, n_id, P)
+    idb = np.where(same == 1, ida, (ida + 1 + rng.randint(0, n_id - 1, P)) % n_id)
+    ka, kb = rng.randint(0, per_id, P), rng.randint(0, per_id, P)
+    kb = np.where((same == 1) & (ka == kb), (kb + 1) % per_id, kb)
+    a, b = ida * per_id + ka, idb * per_id + kb
+    pairs = np.stack([a, b, same], 1)
+
+    class Synth(FlatPairDataset):
+        def load_id(self, idx):
+            return render(idx)
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        pf = os.path.join(td, "pair.list")
+        with open(pf, "w") as fh:
+            fh.write("".join(f"{u} {v} {s}\n" for u, v, s in pairs))
+        m = _mk("ArcFaceNet", 32, "bf16", seed=5)
+        MU.FlatPairDataset = Synth
+        try:
+            res = MU.cross_validate_kfold(m, pf, "unused", None, DEV, batch_size=512, k_fold=10)
+            # the similarities the protocol ran on, recomputed through the same product calls
+            ids = np.unique(pairs[:, :2])
+            emb = MU.embed_ids(m, ids.tolist(), Synth(pairs, "unused").load_id, 512, DEV)
+        finally:
+            MU.FlatPairDataset = FlatPairDataset
+    from frx import ops
+    pos = {int(v): i for i, v in enumerate(ids)}
+    ia = torch.tensor([pos[int(v)] for v in a], device=DEV)
+    ib = torch.tensor([pos[int(v)] for v in b], device=DEV)
+    cos = ops.pair_cosine(emb[ia].contiguous(), emb[ib].contiguous()).cpu().numpy()
+    (ma, sa, mu, su), _, _ = OV.cross_validate_kfold(cos, same, 10)
+    print(f"6000-pair protocol: product acc {res[0]:.3f} +- {res[1]:.3f}, auc {res[2]:.4f}; oracle protocol acc {ma:.3f}, auc {mu:.4f}")
+    assert res[0] == pytest.approx(ma, abs=0.2) and res[1] == pytest.approx(sa, abs=0.2)
+    assert res[2] == pytest.approx(mu, abs=2e-3)
+    assert 60.0 < res[0] < 99.9, "the synthetic task must neither be chance nor trivially separable"
+    # the pair-cosine kernel against numpy on the same embeddings (exact algorithmic check at full size)
+    e = emb.cpu().numpy().astype(np.float64)
+    ref_cos = OV.pair_cosine(e[ia.cpu().numpy()], e[ib.cpu().numpy()], dtype=np.float64)
+    assert np.abs(cos - ref_cos).max() < 1e-5
+    # a subset through the fp32 parity engine against the CPU oracle NETWORK holding the same weights
+    m32 = _mk("ArcFaceNet", 32, "f32", seed=5)
+    ref = FaceNet(H.ARC, 32)
+    ref.backbone.load_state_dict({k[len("backbone."):]: v.cpu() for k, v in m32.state_dict().items() if k.startswith("backbone.")})
+    sub = np.arange(24)
+    imgs_a = torch.stack([render(v) for v in a[sub]]); imgs_b = torch.stack([render(v) for v in b[sub]])
+    m32.eval(); ref.eval()
+    with torch.no_grad():
+        ca = ops.pair_cosine(m32(imgs_a.to(DEV)).float().contiguous(), m32(imgs_b.to(DEV)).float().contiguous()).cpu().numpy()
+        cr = OV.pair_cosine(ref(imgs_a).numpy(), ref(imgs_b).numpy())
+    assert np.abs(ca - cr).max() < 1e-3

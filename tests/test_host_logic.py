@@ -187,45 +187,3 @@ def test_model_classes_keep_reference_contract():
     sd["backbone.fc.bias"] += 1
     m.load_state_dict(sd)
     assert torch.equal(m.backbone.fc.bias.detach(), sd["backbone.fc.bias"])
-
-
-def test_bucket_ranges():
-    from frx.ddp import bucket_ranges
-    r = bucket_ranges(29976448, 4)
-    assert r[0][1] == 29976448 and r[-1][0] == 0
-    assert sorted(lo for lo, _ in r) == sorted(set(lo for lo, _ in r))
-    covered = sorted(r)
-    assert all(a[1] == b[0] for a, b in zip(covered, covered[1:])) and all(lo % 256 == 0 for lo, _ in r)
-    assert bucket_ranges(10, 4) == [(0, 10)]
-
-
-def _ddp_worker(rank, world, port, out):
-    import torch.distributed as dist
-    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    from frx import ddp
-    flat = torch.arange(1000, dtype=torch.float32) * (rank + 1)
-    ddp.GradAllReducer(None, n_buckets=3, via_host=False)(flat)           # CPU tensors: gloo reduces them directly
-    flat2 = torch.full((7,), float(rank + 1))
-    ddp.GradAllReducer(None, n_buckets=2, via_host=True)(flat2)
-    ty = torch.tensor([float(rank + 2)])
-    cnt = ddp.TargetCosineAllReducer(16, None, via_host=True)(ty)
-    out.put((rank, flat.sum().item(), flat2.tolist(), ty.item(), cnt))
-    dist.destroy_process_group()
-
-
-def test_gradient_allreduce_world2_gloo():
-    """N>1 rehearsal on the CPU: bucketed SUM all-reduce and the CurricularFace target-cosine exchange."""
-    import torch.multiprocessing as mp
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = 29500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted(q.get(timeout=120) for _ in procs)
-    for p in procs:
-        p.join(60)
-    expect = float(torch.arange(1000, dtype=torch.float32).sum() * 3)
-    for rank, s, f2, ty, cnt in res:
-        assert s == pytest.approx(expect) and f2 == [3.0] * 7 and ty == 5.0 and cnt == 32
