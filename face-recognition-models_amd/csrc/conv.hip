@@ -18,8 +18,9 @@ static int launch_igemm(hipStream_t st, ConvArgs a, int dtype) {
   FRX_CHECK_ARG(xb < 0x80000000ull && wb < 0x80000000ull && yb < 0x80000000ull,
                 "igemm: tensors must stay below 2 GiB (32-bit buffer offsets)");
   a.xbytes = (unsigned)xb; a.wbytes = (unsigned)wb;
-  TileCfg c = pick_tile(a.M, a.Ncol);
-  if (a.Ncol % c.bn != 0) c = TileCfg{c.bm, 64};
+  TileCfg c = pick_tile(a.M, a.Ncol, a.mode == MODE_STEM, a.mode != MODE_DGRAD);
+  if (a.Ncol % c.bn != 0) c = TileCfg{c.bm, 64, 4, 64};
+  FRX_CHECK_ARG(c.kc == 64 || (a.Kc * (int)esz) % c.kc == 0, "igemm: %d channels do not fill %d-byte K-chunks", a.Kc, c.kc);
   a.tilesM = cdiv(a.M, c.bm);
   a.tilesN = cdiv(a.Ncol, c.bn);
   const int grid = (int)round_up(a.tilesM, 8) * a.tilesN;
@@ -61,7 +62,7 @@ using namespace frx;
 extern "C" int frx_conv_stat_rows(const frx_conv_desc* d) {
   if (check_conv(d) != FRX_OK) return -1;
   const long M = (long)d->N * d->Ho * d->Wo;
-  return cdiv(M, pick_tile(M, d->Co).bm);
+  return cdiv(M, pick_tile(M, d->Co, d->stem != 0, true).bm);
 }
 
 extern "C" int frx_stem_padded_dims(int Hi, int Wi, int* Hp, int* Wp) {
@@ -159,7 +160,7 @@ extern "C" int frx_conv_dgrad_bn(int device, frx_stream_t stream, const frx_conv
 extern "C" int frx_conv_dgrad_stat_rows(const frx_conv_desc* d) {
   if (check_conv(d) != FRX_OK) return -1;
   const long M = (long)d->N * d->Hi * d->Wi;
-  return cdiv(M, pick_tile(M, d->Ci).bm);
+  return cdiv(M, pick_tile(M, d->Ci, false, false).bm);
 }
 
 // Geometry shared by the per-layer and the grouped launches; the pixel split is the caller's policy.

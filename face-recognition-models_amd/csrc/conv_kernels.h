@@ -103,6 +103,13 @@ __device__ __forceinline__ void buf_load8(__amdgpu_buffer_rsrc_t rsrc, unsigned 
 // h = {0,2,3,1}, makes every 16-lane service group hit 16 distinct slots.
 __device__ __forceinline__ int swz64(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }
 
+// Same for [rows][128 B] images (K-chunks of 128 bytes, 8 slots per row, a 256-byte bank row holds two rows): XOR-ing the
+// slot with (row >> 1) & 7 gives the even rows -- and the odd rows -- of every 16-lane service group 8 distinct slots.
+template <int KC> __device__ __forceinline__ int swz_row(int row) {
+  if constexpr (KC == 64) return swz64(row);
+  else return (row >> 1) & 7;
+}
+
 // Weight-fragment row permutation: fragment j, MFMA row fr  ->  channel offset inside the wave's
 // N range, chosen so fragments (2a, 2a+1) give a lane 8 consecutive channels (see the epilogue).
 __device__ __forceinline__ int chan_of(int j, int fr) { return 32 * (j >> 1) + 8 * (fr >> 2) + 4 * (j & 1) + (fr & 3); }
@@ -212,16 +219,19 @@ template <typename T> __device__ __forceinline__ float load_as_float(const void*
 // ------------------------------------------------------------------------------------------
 // MODE (gather geometry) and PRO (BN+ReLU prologue) are compile-time so the steady-state K loop is
 // straight-line code: hipcc then keeps counted s_waitcnt vmcnt(N) for the register ring.
-template <typename T, int BM, int BN, int WM, int WN, int MODE, int PRO, int EPI, bool ADD>   // PRO: 0 none, 1 BN+ReLU, 2 BN-backward affine
+template <typename T, int BM, int BN, int WM, int WN, int MODE, int PRO, int EPI, bool ADD, int KC = 64, int PD = 3>   // PRO: 0 none, 1 BN+ReLU, 2 BN-backward affine; KC: bytes of the contraction axis per row and K-chunk; PD: ring depth
 // waves per SIMD the register budget must allow: 3 where the kernel fits 168 registers without spilling (measured:
 // +10-20 % on the prologue-free variants), 2 for the BN-prologue variants (they spill 35-50 registers at 3)
 // (WM x WN = 4 waves; or 8 waves on a 128x128 tile for launches with too few tiles to give every SIMD two waves)
-__global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 4 : ((PRO == 0 && EPI != EPI_BNBWD_OUT && !ADD) ? 3 : 2)) void k_igemm(ConvArgs a) {
-  constexpr int VEC = TT<T>::VEC, CE = TT<T>::CE;
-  constexpr int NT = 64 * WM * WN, RPP = NT / 4;       // threads; tile rows staged per pass (4 x 16-byte loads per row)
+__global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN == 8 ? 4 : ((PRO == 0 && EPI != EPI_BNBWD_OUT && !ADD) ? 3 : 2))) void k_igemm(ConvArgs a) {
+  constexpr int VEC = TT<T>::VEC, CE = KC / (int)sizeof(T);      // elements per 16-byte load; elements per K-chunk
+  constexpr int CPR = KC / 16;                                   // 16-byte slots per row of the LDS image
+  constexpr int NT = 64 * WM * WN, RPP = NT / CPR;     // threads; tile rows staged per pass (CPR x 16-byte loads per row)
   constexpr int WTM = BM / WM, WTN = BN / WN, FM = WTM / 16, FN = WTN / 16;
   constexpr int ALD = BM / RPP, BLD = BN / RPP;
-  constexpr int STAGE = (BM + BN) * 64;
+  constexpr int STAGE = (BM + BN) * KC;
+  static_assert(KC == 64 || KC == 128, "K-chunk of 64 or 128 bytes");
+  static_assert(MODE != MODE_STEM || KC == 64, "the stem's rows are 64 bytes per tap row");
   static_assert((WM * WN == 4 || WM * WN == 8) && WTM % 16 == 0 && WTN % 32 == 0 && ALD >= 1 && BLD >= 1, "bad wave tiling");
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   // BN scale/shift of the input channels live in LDS: fetching them from global memory at commit
@@ -241,7 +251,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 4 : ((PRO == 0 && EPI 
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int chunk = tid & 3, srow = tid >> 2;
+  const int chunk = tid & (CPR - 1), srow = tid / CPR;
   const T* __restrict__ X = reinterpret_cast<const T*>(a.X);
   const T* __restrict__ Wp = reinterpret_cast<const T*>(a.W);
   const int Ktot = a.R * a.S * a.Kc;
@@ -302,7 +312,6 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 4 : ((PRO == 0 && EPI 
   int tr = 0, ts = 0, c0 = 0;   // current tap (r, s) and channel offset of the K-chunk
   // Register ring of PD K-chunks: HBM/L2 latency (~2k cycles under load) is several chunks of MFMA work,
   // so loads run PD-1 chunks ahead of the LDS write that consumes them.
-  constexpr int PD = 3;
   uint4 ra[PD][ALD], rb[PD][BLD];
   uint4 ra2[PRO == 2 ? PD : 1][ALD];   // second gathered tensor (PRO == 2)
   int rc0[PD];                  // channel offset each ring slot was loaded at (for the BN prologue)
@@ -352,7 +361,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 4 : ((PRO == 0 && EPI 
       m |= (aok[i] ? 1u : 0u) << i;
     }
     rmask[slot] = m;
-    const int sob = kc * 64;
+    const int sob = kc * KC;
 #pragma unroll
     for (int i = 0; i < BLD; ++i) rb[slot][i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rsrcW, bvoff[i], sob, 0));
     // advance the tap walker to chunk kc+1
@@ -368,7 +377,7 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 4 : ((PRO == 0 && EPI 
   auto commit_chunk = [&](int buf, auto slot_tag) {
     constexpr int slot = decltype(slot_tag)::value;
     char* As = smem + buf * STAGE;
-    char* Bs = As + BM * 64;
+    char* Bs = As + BM * KC;
 #pragma unroll
     for (int i = 0; i < ALD; ++i) {
       uint4 v = ra[slot][i];
@@ -385,12 +394,12 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 4 : ((PRO == 0 && EPI 
         __builtin_amdgcn_raw_buffer_store_b128(sv, rsrcDy, avoff[i] + (unsigned)(rc0[slot] * (int)sizeof(T)), 0, 0);
       }
       const int row = srow + RPP * i;
-      *reinterpret_cast<uint4*>(As + (row * 4 + (chunk ^ swz64(row))) * 16) = v;
+      *reinterpret_cast<uint4*>(As + (row * CPR + (chunk ^ swz_row<KC>(row))) * 16) = v;
     }
 #pragma unroll
     for (int i = 0; i < BLD; ++i) {
       const int row = srow + RPP * i;
-      *reinterpret_cast<uint4*>(Bs + (row * 4 + (chunk ^ swz64(row))) * 16) = rb[slot][i];
+      *reinterpret_cast<uint4*>(Bs + (row * CPR + (chunk ^ swz_row<KC>(row))) * 16) = rb[slot][i];
     }
   };
 
@@ -403,86 +412,68 @@ __global__ __launch_bounds__(64 * WM * WN, WM * WN == 8 ? 4 : ((PRO == 0 && EPI 
   const int fr = lane & 15, fq = lane >> 4;
   auto compute_chunk = [&](int cur) {
     const char* As = smem + cur * STAGE;
-    const char* Bs = As + BM * 64;
-    uint4 fa[FM], fb[FN];
+    const char* Bs = As + BM * KC;
 #pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const int row = wm * WTM + i * 16 + fr;
-      fa[i] = *reinterpret_cast<const uint4*>(As + (row * 4 + (fq ^ swz64(row))) * 16);
-    }
+    for (int ks = 0; ks < KC / 64; ++ks) {             // one MFMA k-step = 64 bytes of the contraction axis
+      uint4 fa[FM], fb[FN];
 #pragma unroll
-    for (int j = 0; j < FN; ++j) {
-      const int row = wn * WTN + chan_of(j, fr);
-      fb[j] = *reinterpret_cast<const uint4*>(Bs + (row * 4 + (fq ^ swz64(row))) * 16);
-    }
-    // Operands are swapped (weights first): D[row = channel][col = pixel], so a lane ends up with
-    // 4 CONSECUTIVE channels of one pixel per fragment -- contiguous in NHWC memory.
-#pragma unroll
-    for (int i = 0; i < FM; ++i)
+      for (int i = 0; i < FM; ++i) {
+        const int row = wm * WTM + i * 16 + fr;
+        fa[i] = *reinterpret_cast<const uint4*>(As + (row * CPR + ((ks * 4 + fq) ^ swz_row<KC>(row))) * 16);
+      }
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
-        if constexpr (sizeof(T) == 2) {
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&fb[j]),
-                                                              *reinterpret_cast<bf16x8*>(&fa[i]), acc[i][j], 0, 0, 0);
-        } else {
-          const float* pa = reinterpret_cast<const float*>(&fa[i]);
-          const float* pb = reinterpret_cast<const float*>(&fb[j]);
-#pragma unroll
-          for (int q = 0; q < 4; ++q)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(pb[q], pa[q], acc[i][j], 0, 0, 0);
-        }
+        const int row = wn * WTN + chan_of(j, fr);
+        fb[j] = *reinterpret_cast<const uint4*>(Bs + (row * CPR + ((ks * 4 + fq) ^ swz_row<KC>(row))) * 16);
       }
+      // Operands are swapped (weights first): D[row = channel][col = pixel], so a lane ends up with
+      // 4 CONSECUTIVE channels of one pixel per fragment -- contiguous in NHWC memory.
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          if constexpr (sizeof(T) == 2) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&fb[j]),
+                                                                *reinterpret_cast<bf16x8*>(&fa[i]), acc[i][j], 0, 0, 0);
+          } else {
+            const float* pa = reinterpret_cast<const float*>(&fa[i]);
+            const float* pb = reinterpret_cast<const float*>(&fb[j]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(pb[q], pa[q], acc[i][j], 0, 0, 0);
+          }
+        }
+    }
   };
-  using S0 = std::integral_constant<int, 0>;
-  using S1 = std::integral_constant<int, 1>;
-  using S2 = std::integral_constant<int, 2>;
-  static_assert(PD == 3, "the ring below is written out for 3 slots");
-  issue_chunk(0, S0{});
-  if (1 < nk) issue_chunk(1, S1{});
-  if (2 < nk) issue_chunk(2, S2{});
-  commit_chunk(0, S0{});
+  // chunk j lives in ring slot j % PD and in LDS stage j & 1.  One ring step: MFMAs of chunk k, global loads of chunk
+  // k+PD into the slot chunk k just left, registers -> LDS of chunk k+1, barrier.
+  // Steady state: no branch between a load's issue and its wait, so hipcc keeps counted vmcnt(N) waits.
+  auto ring_step = [&](int k, auto u_tag, auto guarded_tag) {
+    constexpr int U = decltype(u_tag)::value;
+    constexpr bool GUARDED = decltype(guarded_tag)::value;
+    compute_chunk(k & 1);
+    if (!GUARDED || k + PD < nk) issue_chunk(k + PD, std::integral_constant<int, U % PD>{});
+    if (!GUARDED || k + 1 < nk) commit_chunk((k + 1) & 1, std::integral_constant<int, (U + 1) % PD>{});
+    __syncthreads();
+  };
+  auto ring_round = [&](int k0, auto guarded_tag) {       // PD consecutive steps starting at a chunk index k0 = 0 (mod PD)
+    constexpr bool GUARDED = decltype(guarded_tag)::value;
+    ring_step(k0, std::integral_constant<int, 0>{}, guarded_tag);
+    if constexpr (PD > 1) { if (!GUARDED || k0 + 1 < nk) ring_step(k0 + 1, std::integral_constant<int, 1>{}, guarded_tag); }
+    if constexpr (PD > 2) { if (!GUARDED || k0 + 2 < nk) ring_step(k0 + 2, std::integral_constant<int, 2>{}, guarded_tag); }
+    if constexpr (PD > 3) { if (!GUARDED || k0 + 3 < nk) ring_step(k0 + 3, std::integral_constant<int, 3>{}, guarded_tag); }
+  };
+  static_assert(PD >= 2 && PD <= 4, "ring depth");
+  issue_chunk(0, std::integral_constant<int, 0>{});
+  if constexpr (PD > 1) { if (1 < nk) issue_chunk(1, std::integral_constant<int, 1>{}); }
+  if constexpr (PD > 2) { if (2 < nk) issue_chunk(2, std::integral_constant<int, 2>{}); }
+  if constexpr (PD > 3) { if (3 < nk) issue_chunk(3, std::integral_constant<int, 3>{}); }
+  commit_chunk(0, std::integral_constant<int, 0>{});
   __syncthreads();
   FRX_STAMP(1);
-  // chunk j lives in ring slot j % 3 and in LDS stage j & 1.
-  // Steady state: no branch between a load's issue and its wait, so hipcc keeps counted vmcnt(N) waits.
   int kc = 0;
-  for (; kc + 5 < nk; kc += 3) {
-    compute_chunk(kc & 1);
-    issue_chunk(kc + 3, S0{});
-    commit_chunk((kc + 1) & 1, S1{});
-    __syncthreads();
-    compute_chunk((kc + 1) & 1);
-    issue_chunk(kc + 4, S1{});
-    commit_chunk((kc + 2) & 1, S2{});
-    __syncthreads();
-    compute_chunk((kc + 2) & 1);
-    issue_chunk(kc + 5, S2{});
-    commit_chunk((kc + 3) & 1, S0{});
-    __syncthreads();
-  }
-  for (; kc < nk; kc += 3) {                  // tail (and the whole loop when K is short)
-    {
-      const int k = kc;
-      compute_chunk(k & 1);
-      if (k + 3 < nk) issue_chunk(k + 3, S0{});
-      if (k + 1 < nk) commit_chunk((k + 1) & 1, S1{});
-      __syncthreads();
-    }
-    if (kc + 1 < nk) {
-      const int k = kc + 1;
-      compute_chunk(k & 1);
-      if (k + 3 < nk) issue_chunk(k + 3, S1{});
-      if (k + 1 < nk) commit_chunk((k + 1) & 1, S2{});
-      __syncthreads();
-    }
-    if (kc + 2 < nk) {
-      const int k = kc + 2;
-      compute_chunk(k & 1);
-      if (k + 3 < nk) issue_chunk(k + 3, S2{});
-      if (k + 1 < nk) commit_chunk((k + 1) & 1, S0{});
-      __syncthreads();
-    }
-  }
+  for (; kc + 2 * PD - 1 < nk; kc += PD) ring_round(kc, std::false_type{});
+  for (; kc < nk; kc += PD) ring_round(kc, std::true_type{});        // tail (and the whole loop when K is short)
 
   // ---- epilogue.  C/D map: col = lane&15 (pixel), row = (lane>>4)*4 + reg (channel slot).
   // Fragment pair (2a, 2a+1) holds, for this lane, channels 32a + 8*fq + [0..8) of pixel fr: 16-byte

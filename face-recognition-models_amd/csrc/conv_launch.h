@@ -3,26 +3,37 @@
 #pragma once
 #include "conv_kernels.h"
 #include <stdlib.h>
+#include <stdio.h>
 
 namespace frx {
 
-struct TileCfg { int bm, bn; };
+struct TileCfg { int bm, bn, waves, kc; };       // block tile (pixels x channels), waves per block, K-chunk bytes
 
-static inline TileCfg pick_tile(long M, int Ncol) {
-  if (const char* e = getenv("FRX_IGEMM_TILE")) {           // tuning aid: "128x128" | "128x64" | "64x64"
-    if (e[0] == '6') return {64, 64};
-    if (e[0] == '1' && e[4] == '6') return {128, 64};
-    if (e[0] == '1' && Ncol % 128 == 0) return {128, 128};
-  }
-  if (Ncol <= 64) return {128, 64};
-  // measured per ResNet-50 shape (scripts/tile_sweep.py): the square 128x128 tile wins down to ~3/4 of a wave of
-  // blocks (twice the MFMA work per staged byte and per prologue evaluation); below that the 64x64 tile's 4x
-  // block count beats the 128x64 one's 2x.  The 128x128 tile runs EIGHT waves (2x4, 64x32 each): half the
-  // staging work and accumulators per wave keep it under 128 registers, i.e. 16 waves per CU instead of 8 --
-  // 5-15 % on the forward convs, 3-10 % on the dgrads over four 64x64 waves.
+// tuning aid: FRX_IGEMM_TILE = "BMxBNxWAVESxKC" out of the list FRX_IGEMM_LAUNCH instantiates
+static inline bool tile_from_env(TileCfg* c) {
+  const char* e = getenv("FRX_IGEMM_TILE");
+  if (!e) return false;
+  int bm, bn, w, kc;
+  if (sscanf(e, "%dx%dx%dx%d", &bm, &bn, &w, &kc) != 4) return false;
+  *c = TileCfg{bm, bn, w, kc};
+  return true;
+}
+
+// `fwd`: forward / stem (operand A = activations); false: input gradient
+static inline TileCfg pick_tile(long M, int Ncol, bool stem = false, bool fwd = true) {
+  TileCfg c;
+  if (tile_from_env(&c) && Ncol % c.bn == 0 && !(stem && c.kc != 64)) return c;
+  if (Ncol <= 64) return {128, 64, 4, 64};
+  // measured per ResNet-50 shape (scripts/tile_ab.py): the square 128x128 tile wins down to ~3/4 of a wave of
+  // blocks (twice the MFMA work per staged byte and per prologue evaluation).  It runs EIGHT waves (2x4, 64x32 each):
+  // half the staging work and accumulators per wave keep it under 128 registers, i.e. 16 waves per CU instead of 8.
   const long mt128 = (M + 127) / 128;
-  if (mt128 * ((Ncol + 127) / 128) >= 192) return {128, 128};
-  return {64, 64};
+  if (mt128 * ((Ncol + 127) / 128) >= 192) return {128, 128, 8, 64};
+  // fewer tiles than that (layer4, M = 4096): forward convs take 64 pixels x 128 channels on four waves side by side
+  // (1x4) with 128-byte K-chunks -- the activation rows are read in whole 128-byte lines and every wave shares the one
+  // pixel tile (3x3 57 -> 48 us, 2048->512 33 -> 28 us); the input gradients stay on the 64x64 tile (measured equal or better)
+  if (fwd && Ncol % 128 == 0 && ((M + 63) / 64) * (Ncol / 128) >= 192) return {64, 128, 4, 128};
+  return {64, 64, 4, 64};
 }
 
 // each returns FRX_OK / FRX_ERR_*; `a` is completed (tiles, byte sizes) by the caller
@@ -34,16 +45,30 @@ int launch_igemm_dgrad_bn(hipStream_t st, const ConvArgs& a, int dtype, TileCfg 
 int launch_wgrad(hipStream_t st, const WgradArgs& a, int dtype, int bt, int wmode, bool pro, bool ypro, int grid);
 int launch_wgrad_grouped(hipStream_t st, int dtype, const WgradArgs* layers, const WgradItem* items, int nitems);
 
-#define FRX_IGEMM_LAUNCH(T_, MODE_, PRO_, EPI_, ADD_)                                                                     \
-  do {                                                                                                                    \
-    if (c.bm == 128 && c.bn == 128) hipLaunchKernelGGL((k_igemm<T_, 128, 128, 2, 4, MODE_, PRO_, EPI_, ADD_>), dim3(grid), dim3(512), 0, st, a); \
-    else if (c.bm == 128 && c.bn == 64) hipLaunchKernelGGL((k_igemm<T_, 128, 64, 2, 2, MODE_, PRO_, EPI_, ADD_>), dim3(grid), dim3(256), 0, st, a); \
-    else hipLaunchKernelGGL((k_igemm<T_, 64, 64, 2, 2, MODE_, PRO_, EPI_, ADD_>), dim3(grid), dim3(256), 0, st, a);       \
+#define FRX_IGEMM_K(T_, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, ADD_, KC_) \
+  hipLaunchKernelGGL((k_igemm<T_, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, ADD_, KC_>), dim3(grid), dim3(64 * WM_ * WN_), 0, st, a)
+#define FRX_IGEMM_LAUNCH64(T_, MODE_, PRO_, EPI_, ADD_)                                                                    \
+  do {                                                                                                                     \
+    if (c.bm == 128 && c.bn == 128) FRX_IGEMM_K(T_, 128, 128, 2, 4, MODE_, PRO_, EPI_, ADD_, 64);                           \
+    else if (c.bm == 128 && c.bn == 64) FRX_IGEMM_K(T_, 128, 64, 2, 2, MODE_, PRO_, EPI_, ADD_, 64);                        \
+    else FRX_IGEMM_K(T_, 64, 64, 2, 2, MODE_, PRO_, EPI_, ADD_, 64);                                                        \
+  } while (0)
+#define FRX_IGEMM_LAUNCH(T_, MODE_, PRO_, EPI_, ADD_)                                                                      \
+  do {                                                                                                                     \
+    if (c.kc == 128 && c.bm == 64 && c.bn == 128) FRX_IGEMM_K(T_, 64, 128, 1, 4, MODE_, PRO_, EPI_, ADD_, 128);             \
+    else FRX_IGEMM_LAUNCH64(T_, MODE_, PRO_, EPI_, ADD_);                                                                  \
   } while (0)
 #define FRX_IGEMM_DT(MODE_, PRO_, EPI_, ADD_)                                   \
   do {                                                                          \
     if (dtype == FRX_BF16) FRX_IGEMM_LAUNCH(bf16_t, MODE_, PRO_, EPI_, ADD_);   \
     else FRX_IGEMM_LAUNCH(float, MODE_, PRO_, EPI_, ADD_);                      \
+  } while (0)
+
+// (the stem's rows are 64 bytes per tap row: 64-byte K-chunks only)
+#define FRX_IGEMM_DT64(MODE_, PRO_, EPI_, ADD_)                                   \
+  do {                                                                            \
+    if (dtype == FRX_BF16) FRX_IGEMM_LAUNCH64(bf16_t, MODE_, PRO_, EPI_, ADD_);   \
+    else FRX_IGEMM_LAUNCH64(float, MODE_, PRO_, EPI_, ADD_);                      \
   } while (0)
 
 }  // namespace frx

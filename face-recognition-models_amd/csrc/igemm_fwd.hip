@@ -16,8 +16,8 @@ int launch_igemm_fwd(hipStream_t st, const ConvArgs& a, int dtype, TileCfg c, in
   return FRX_OK;
 }
 int launch_igemm_stem(hipStream_t st, const ConvArgs& a, int dtype, TileCfg c, int grid, int epi) {
-  if (epi == EPI_STATS) FRX_IGEMM_DT(MODE_STEM, 0, EPI_STATS, false);
-  else FRX_IGEMM_DT(MODE_STEM, 0, EPI_PLAIN, false);
+  if (epi == EPI_STATS) FRX_IGEMM_DT64(MODE_STEM, 0, EPI_STATS, false);
+  else FRX_IGEMM_DT64(MODE_STEM, 0, EPI_PLAIN, false);
   FRX_LAUNCH_CHECK();
   return FRX_OK;
 }
