@@ -202,6 +202,7 @@ struct HeadConst {
   float s, cos_m, sin_m, th, mm, m, lamb;
   float p0, p1, p2, p3;   // per-kind parameters (frx_head_desc::p)
   int flags;
+  int c0;                 // class-sharded head: global index of this shard's first class (labels are global)
 };
 
 struct RowCtx {   // per-row values
@@ -383,22 +384,31 @@ __device__ __forceinline__ void head_z(float cc, bool target, const HeadConst& h
 // A label outside [0, C) (a class-count mismatch between the dataset folders and num_classes) must not become an
 // out-of-bounds access: every kernel indexes with the label clamped into range, and the row's loss is poisoned with
 // NaN so the mistake shows at the caller's next loss read (the reference's CrossEntropyLoss raises there).
+// Class-sharded head (flags bit 3): the desc describes columns [c0, c0 + C) of a wider head; labels stay global, and a
+// label outside the shard is simply a row whose target lives on another rank (owned = false, not an error).
 __device__ __forceinline__ int safe_label(int64_t y, int C, bool& bad) {
   bad = y < 0 || y >= (int64_t)C;
   return bad ? 0 : (int)y;
 }
+__device__ __forceinline__ int shard_label(int64_t y, const HeadConst& h, int C, bool& owned, bool& bad) {
+  const int64_t yl = y - (int64_t)h.c0;
+  owned = yl >= 0 && yl < (int64_t)C;
+  bad = !owned && !(h.flags & 8);
+  return owned ? (int)yl : -1;          // -1 never equals a column index
+}
 
 // target cosine per row (clamped as the head clamps), and its sum over the batch
 template <int KIND>
-__global__ __launch_bounds__(256) void k_head_ty(const float* __restrict__ cbuf, int N, long ldc, int C,
+__global__ __launch_bounds__(256) void k_head_ty(HeadConst h, const float* __restrict__ cbuf, int N, long ldc, int C,
                                                  const int64_t* __restrict__ labels,
                                                  float* __restrict__ ty, float* __restrict__ ty_sum) {
   __shared__ float sh[4];
   float part = 0.f;
   for (int n = threadIdx.x; n < N; n += 256) {
-    bool bad;
-    const int y = safe_label(labels[n], C, bad);
-    const float v = bad ? NAN : head_clamp<KIND>(cbuf[(long)n * ldc + y]);
+    bool bad, owned;
+    const int y = shard_label(labels[n], h, C, owned, bad);
+    // (a row whose target sits in another shard contributes 0: the caller's SUM all-reduce assembles the global vector)
+    const float v = bad ? NAN : (owned ? head_clamp<KIND>(cbuf[(long)n * ldc + y]) : 0.f);
     ty[n] = v;
     part += v;
   }
@@ -552,16 +562,19 @@ __global__ __launch_bounds__(256) void k_head_rows(HeadConst h, const float* __r
                                                    float* __restrict__ logits_out,
                                                    float* __restrict__ lse_out,
                                                    float* __restrict__ rowloss,
-                                                   int32_t* __restrict__ rowrank) {
+                                                   int32_t* __restrict__ rowrank,
+                                                   float* __restrict__ part /* shard mode: [3][N] max, sum-exp, rank */) {
   __shared__ float sh[4];
   __shared__ int shi[4];
   if (KIND == FRX_SPHERE && (h.flags & 4)) h.lamb = *state_t;
   const int n = blockIdx.x;
-  bool bad_label;
-  const int y = safe_label(labels[n], C, bad_label);
+  bool bad_label, owned;
+  const int y = shard_label(labels[n], h, C, owned, bad_label);
   const float* crow = cbuf + (long)n * ldc;
   const RowCtx r = make_row_ctx(KIND, n, h, xnorm, ty, state_t, rowp);
-  const float cy = head_clamp<KIND>(crow[y]);
+  // the clamped target cosine: k_head_ty left it in ty[] (in shard mode the caller put the all-reduced vector there,
+  // so every shard sees the row's target cosine although only one of them holds the column)
+  const float cy = ty[n];
   const float cos_s_y = head_cos_s<KIND>(cy, h, r);
   float zy, dummy, u;
   head_z<KIND>(cy, true, h, r, zy, dummy, u);
@@ -609,11 +622,44 @@ __global__ __launch_bounds__(256) void k_head_rows(HeadConst h, const float* __r
   if ((threadIdx.x & 63) == 0) shi[threadIdx.x >> 6] = rank;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const float lse = zmax + logf(se);
-    if (lse_out) lse_out[n] = lse;
-    rowloss[n] = bad_label ? NAN : lse - zy;
-    rowrank[n] = shi[0] + shi[1] + shi[2] + shi[3];
+    const int rk = shi[0] + shi[1] + shi[2] + shi[3];
+    if (part) {                         // partial softmax statistics of this shard's columns
+      const int N = gridDim.x;
+      part[n] = zmax; part[N + n] = se; part[2 * N + n] = (float)rk;
+    } else {
+      const float lse = zmax + logf(se);
+      if (lse_out) lse_out[n] = lse;
+      rowloss[n] = bad_label ? NAN : lse - zy;
+      rowrank[n] = rk;
+    }
   }
+}
+
+// shard mode, after the partial statistics were combined across shards: part_sum[n] *= exp(local max - global max)
+__global__ __launch_bounds__(256) void k_shard_rescale(int N, const float* __restrict__ lmax, const float* __restrict__ gmax,
+                                                       float* __restrict__ psum) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n < N) psum[n] *= expf(lmax[n] - gmax[n]);
+}
+
+// shard mode: per-row loss and rank from the GLOBAL max / sum-exp / rank (identical on every shard)
+template <int KIND>
+__global__ __launch_bounds__(256) void k_shard_finish(HeadConst h, int N, const float* __restrict__ xnorm,
+                                                      const float* __restrict__ ty, const float* __restrict__ state_t,
+                                                      const float* __restrict__ rowp, const float* __restrict__ gmax,
+                                                      const float* __restrict__ gsum, const float* __restrict__ grank,
+                                                      float* __restrict__ lse_ws, float* __restrict__ rowloss,
+                                                      int32_t* __restrict__ rowrank) {
+  if (KIND == FRX_SPHERE && (h.flags & 4)) h.lamb = *state_t;
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const RowCtx r = make_row_ctx(KIND, n, h, xnorm, ty, state_t, rowp);
+  float zy, d, u;
+  head_z<KIND>(ty[n], true, h, r, zy, d, u);
+  const float lse = gmax[n] + logf(gsum[n]);
+  lse_ws[n] = lse;
+  rowloss[n] = lse - zy;
+  rowrank[n] = (int)(grank[n] + 0.5f);
 }
 
 // loss = mean(rowloss); topk = (#rank<1, #rank<5).  Single block: deterministic order.
@@ -656,8 +702,8 @@ __global__ __launch_bounds__(256) void k_head_grad(HeadConst h, const float* __r
   __shared__ float sh[4];
   if (KIND == FRX_SPHERE && (h.flags & 4)) h.lamb = *state_t;
   const int n = blockIdx.x;
-  bool bad_label;
-  const int y = safe_label(labels[n], C, bad_label);
+  bool bad_label, owned;
+  const int y = shard_label(labels[n], h, C, owned, bad_label);
   const float* crow = cbuf + (long)n * Cpad;
   float* grow = gbuf + (long)n * Cpad;
   const RowCtx r = make_row_ctx(KIND, n, h, xnorm, ty, state_t, rowp);
@@ -842,6 +888,11 @@ static int check_desc(const frx_head_desc* d) {
   FRX_CHECK_ARG(d->kind != FRX_MAG || (d->p[3] > d->p[2] && d->p[2] > 0.f), "MagFace needs 0 < l_a < u_a (got %g, %g)",
                 (double)d->p[2], (double)d->p[3]);
   FRX_CHECK_ARG(d->kind != FRX_ADA || d->N > 1, "AdaFace's batch std needs N > 1");
+  if (d->flags & 8) {
+    FRX_CHECK_ARG(d->kind == FRX_ARC || d->kind == FRX_COS || d->kind == FRX_SPHERE || d->kind == FRX_CURR || d->kind == FRX_MV_AM ||
+                  d->kind == FRX_MV_ARC, "class-sharded mode supports ARC / COS / SPHERE / CURR / MV_* (kind %d keeps batch- or class-wide state)", d->kind);
+    FRX_CHECK_ARG(d->class_offset >= 0, "class_offset must be >= 0");
+  }
   return FRX_OK;
 }
 
@@ -857,6 +908,7 @@ static HeadConst make_const(const frx_head_desc* d) {
   h.lamb = d->lamb;
   h.p0 = d->p[0]; h.p1 = d->p[1]; h.p2 = d->p[2]; h.p3 = d->p[3];
   h.flags = d->flags;
+  h.c0 = (d->flags & 8) ? d->class_offset : 0;
   return h;
 }
 
@@ -921,7 +973,8 @@ extern "C" int frx_head_fwd_cos(int device, frx_stream_t stream, const frx_head_
   g.C = W.cbuf; g.ldc = W.Cpad; g.row_scale = W.xinv; g.col_scale = W.winv;
   if (int rc = launch_gemm(st, g, 1)) return rc;
   float* tys = ty_sum_out ? ty_sum_out : W.tysum;
-#define FRX_TY(K) hipLaunchKernelGGL(k_head_ty<K>, dim3(1), dim3(256), 0, st, W.cbuf, d->N, (long)W.Cpad, d->C, labels, W.ty, tys)
+  const HeadConst hc = make_const(d);
+#define FRX_TY(K) hipLaunchKernelGGL(k_head_ty<K>, dim3(1), dim3(256), 0, st, hc, W.cbuf, d->N, (long)W.Cpad, d->C, labels, W.ty, tys)
   FRX_KIND_SWITCH(d->kind, FRX_TY)
 #undef FRX_TY
   FRX_LAUNCH_CHECK();
@@ -951,7 +1004,7 @@ extern "C" int frx_head_vpl_prepare(int device, frx_stream_t stream, const frx_h
   if (int rc = launch_gemm(st, g, 1)) return rc;
   hipLaunchKernelGGL(k_vpl_blend, dim3(d->N), dim3(256), 0, st, W.cbuf, (const float*)W.cbuf2, (const float*)life, labels,
                      d->C, (long)W.Cpad, d->p[0]);
-  hipLaunchKernelGGL(k_head_ty<FRX_VPL>, dim3(1), dim3(256), 0, st, W.cbuf, d->N, (long)W.Cpad, d->C, labels, W.ty, W.tysum);
+  hipLaunchKernelGGL(k_head_ty<FRX_VPL>, dim3(1), dim3(256), 0, st, make_const(d), W.cbuf, d->N, (long)W.Cpad, d->C, labels, W.ty, W.tysum);
   FRX_LAUNCH_CHECK();
   return FRX_OK;
 }
@@ -979,11 +1032,12 @@ extern "C" int frx_head_fwd_loss(int device, frx_stream_t stream, const frx_head
   if (d->kind == FRX_MAG)
     hipLaunchKernelGGL(k_head_rowparam<FRX_MAG>, dim3(1), dim3(256), 0, st, h, (const float*)W.xnorm, d->N, state_t, W.rowp, W.xn, W.lossg);
   FRX_LAUNCH_CHECK();
+  FRX_CHECK_ARG(!(d->flags & 8), "head_fwd_loss: a class-sharded head (flags bit 3) runs frx_head_shard_rows / _finish instead");
   const float* rowp = (d->kind == FRX_ELASTIC_ARC || d->kind == FRX_ELASTIC_COS) ? (const float*)state_t : (const float*)W.rowp;
 #define FRX_ROWS(K)                                                                                   \
   hipLaunchKernelGGL(k_head_rows<K>, dim3(d->N), dim3(256), 0, st, h, (const float*)W.cbuf, d->C,     \
                      (long)W.Cpad, labels, (const float*)W.xnorm, (const float*)W.ty,                 \
-                     (const float*)state_t, rowp, cos_s, logits, W.lse, W.rowloss, W.rowrank)
+                     (const float*)state_t, rowp, cos_s, logits, W.lse, W.rowloss, W.rowrank, (float*)nullptr)
   FRX_KIND_SWITCH(d->kind, FRX_ROWS)
 #undef FRX_ROWS
   FRX_LAUNCH_CHECK();
@@ -994,6 +1048,86 @@ extern "C" int frx_head_fwd_loss(int device, frx_stream_t stream, const frx_head
   if (lse) hipLaunchKernelGGL(k_copy_f32, dim3(cdiv(d->N, 256)), dim3(256), 0, st, (const float*)W.lse, lse, (long)d->N);
   if (norms) hipLaunchKernelGGL(k_copy_f32, dim3(cdiv(d->N, 256)), dim3(256), 0, st,
                                 (const float*)(d->kind == FRX_MAG ? W.xn : W.xnorm), norms, (long)d->N);
+  FRX_LAUNCH_CHECK();
+  return FRX_OK;
+}
+
+// ---------------------------------------------------------------------------------------- class-sharded head
+extern "C" int frx_head_shard_cos(int device, frx_stream_t stream, const frx_head_desc* d, const float* x, const float* w,
+                                  const int64_t* labels, void* ws, size_t ws_bytes, float* ty_out) {
+  FRX_CHECK_ARG(d && (d->flags & 8), "head_shard_cos: the descriptor is not in class-sharded mode (flags bit 3)");
+  FRX_CHECK_ARG(ty_out != nullptr, "head_shard_cos: ty_out is NULL");
+  if (int rc = frx_head_fwd_cos(device, stream, d, x, w, labels, ws, ws_bytes, nullptr)) return rc;
+  FRX_ENTER(device);
+  HeadWs W = carve(d, ws);
+  hipLaunchKernelGGL(k_copy_f32, dim3(cdiv(d->N, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)W.ty, ty_out, (long)d->N);
+  FRX_LAUNCH_CHECK();
+  return FRX_OK;
+}
+
+__global__ __launch_bounds__(256) void k_shard_take_ty(const float* __restrict__ tyg, int N, float* __restrict__ ty, float* __restrict__ ty_sum) {
+  __shared__ float sh[4];
+  float part = 0.f;
+  for (int n = threadIdx.x; n < N; n += 256) { const float v = tyg[n]; ty[n] = v; part += v; }
+  const float tot = block_sum256(part, sh);
+  if (threadIdx.x == 0) *ty_sum = tot;
+}
+
+extern "C" int frx_head_shard_rows(int device, frx_stream_t stream, const frx_head_desc* d, const int64_t* labels,
+                                   float* state_t, const float* ty_global, void* ws, size_t ws_bytes, float* part) {
+  if (int rc = check_desc(d)) return rc;
+  FRX_CHECK_ARG(d->flags & 8, "head_shard_rows: the descriptor is not in class-sharded mode (flags bit 3)");
+  FRX_CHECK_ARG(labels && ty_global && ws && part, "head_shard_rows: NULL pointer");
+  FRX_CHECK_ARG(!needs_state_d(d) || state_t, "%s", state_what(d->kind));
+  FRX_ENTER(device);
+  hipStream_t st = (hipStream_t)stream;
+  HeadWs W = carve(d, ws);
+  if (ws_bytes < W.bytes) { set_error("head workspace too small: %zu < %zu", ws_bytes, W.bytes); return FRX_ERR_WORKSPACE; }
+  HeadConst h = make_const(d);
+  // the all-reduced target cosines replace this shard's partial vector; their sum over ALL rows feeds CurricularFace's EMA
+  hipLaunchKernelGGL(k_shard_take_ty, dim3(1), dim3(256), 0, st, ty_global, d->N, W.ty, W.tysum);
+  if (d->kind == FRX_CURR)
+    hipLaunchKernelGGL(k_curr_t_update, dim3(1), dim3(64), 0, st, state_t, (const float*)W.tysum, 1.f / (float)d->N, d->momentum);
+  FRX_LAUNCH_CHECK();
+#define FRX_ROWS(K)                                                                                   \
+  hipLaunchKernelGGL(k_head_rows<K>, dim3(d->N), dim3(256), 0, st, h, (const float*)W.cbuf, d->C,     \
+                     (long)W.Cpad, labels, (const float*)W.xnorm, (const float*)W.ty,                 \
+                     (const float*)state_t, (const float*)W.rowp, (float*)nullptr, (float*)nullptr, W.lse, W.rowloss, W.rowrank, part)
+  FRX_KIND_SWITCH(d->kind, FRX_ROWS)
+#undef FRX_ROWS
+  FRX_LAUNCH_CHECK();
+  return FRX_OK;
+}
+
+extern "C" int frx_head_shard_rescale(int device, frx_stream_t stream, int N, const float* local_max, const float* global_max,
+                                      float* part_sum) {
+  FRX_CHECK_ARG(N > 0 && local_max && global_max && part_sum, "head_shard_rescale: bad args");
+  FRX_ENTER(device);
+  hipLaunchKernelGGL(k_shard_rescale, dim3(cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, N, local_max, global_max, part_sum);
+  FRX_LAUNCH_CHECK();
+  return FRX_OK;
+}
+
+extern "C" int frx_head_shard_finish(int device, frx_stream_t stream, const frx_head_desc* d, const float* state_t,
+                                     const float* global_max, const float* global_sum, const float* global_rank, void* ws,
+                                     size_t ws_bytes, float* norms, float* loss, float* lse, int32_t* topk) {
+  if (int rc = check_desc(d)) return rc;
+  FRX_CHECK_ARG(d->flags & 8, "head_shard_finish: the descriptor is not in class-sharded mode (flags bit 3)");
+  FRX_CHECK_ARG(global_max && global_sum && global_rank && ws && loss, "head_shard_finish: NULL pointer");
+  FRX_ENTER(device);
+  hipStream_t st = (hipStream_t)stream;
+  HeadWs W = carve(d, ws);
+  if (ws_bytes < W.bytes) { set_error("head workspace too small: %zu < %zu", ws_bytes, W.bytes); return FRX_ERR_WORKSPACE; }
+  HeadConst h = make_const(d);
+#define FRX_FIN(K)                                                                                                        \
+  hipLaunchKernelGGL(k_shard_finish<K>, dim3(cdiv(d->N, 256)), dim3(256), 0, st, h, d->N, (const float*)W.xnorm,           \
+                     (const float*)W.ty, state_t, (const float*)W.rowp, global_max, global_sum, global_rank, W.lse, W.rowloss, W.rowrank)
+  FRX_KIND_SWITCH(d->kind, FRX_FIN)
+#undef FRX_FIN
+  hipLaunchKernelGGL(k_head_finalize, dim3(1), dim3(256), 0, st, (const float*)W.rowloss, (const int32_t*)W.rowrank, d->N, loss,
+                     topk, (float*)nullptr);
+  if (lse) hipLaunchKernelGGL(k_copy_f32, dim3(cdiv(d->N, 256)), dim3(256), 0, st, (const float*)W.lse, lse, (long)d->N);
+  if (norms) hipLaunchKernelGGL(k_copy_f32, dim3(cdiv(d->N, 256)), dim3(256), 0, st, (const float*)W.xnorm, norms, (long)d->N);
   FRX_LAUNCH_CHECK();
   return FRX_OK;
 }

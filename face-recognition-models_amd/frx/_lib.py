@@ -17,7 +17,7 @@ class FrxError(RuntimeError):
 class HeadDesc(C.Structure):
     _fields_ = [("kind", C.c_int32), ("N", C.c_int32), ("D", C.c_int32), ("C", C.c_int32),
                 ("s", C.c_float), ("m", C.c_float), ("momentum", C.c_float), ("lamb", C.c_float),
-                ("p", C.c_float * 4), ("flags", C.c_int32), ("reserved", C.c_int32)]
+                ("p", C.c_float * 4), ("flags", C.c_int32), ("class_offset", C.c_int32)]
 
 
 class ConvDesc(C.Structure):
@@ -56,6 +56,10 @@ _SIGS = {
                                _P, _P, _P, _P, _P, _P]),
     "frx_head_bwd": (C.c_int, [C.c_int, _P, C.POINTER(HeadDesc), _P, _P, _P, _P, _P, _P, C.c_size_t,
                                _P, _P, C.c_int]),
+    "frx_head_shard_cos": (C.c_int, [C.c_int, _P, C.POINTER(HeadDesc), _P, _P, _P, _P, C.c_size_t, _P]),
+    "frx_head_shard_rows": (C.c_int, [C.c_int, _P, C.POINTER(HeadDesc), _P, _P, _P, _P, C.c_size_t, _P]),
+    "frx_head_shard_rescale": (C.c_int, [C.c_int, _P, C.c_int, _P, _P, _P]),
+    "frx_head_shard_finish": (C.c_int, [C.c_int, _P, C.POINTER(HeadDesc), _P, _P, _P, _P, _P, C.c_size_t, _P, _P, _P, _P]),
     "frx_head_aux": (C.c_int, [C.c_int, _P, C.POINTER(HeadDesc), _P, _P, C.c_size_t, _P, _P]),
     "frx_head_vpl_prepare": (C.c_int, [C.c_int, _P, C.POINTER(HeadDesc), _P, _P, _P, _P, C.c_size_t]),
     "frx_conv_stat_rows": (C.c_int, [C.POINTER(ConvDesc)]),

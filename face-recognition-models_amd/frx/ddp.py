@@ -67,7 +67,7 @@ class DataParallelStep:
         self._key = None               # engine.graph_key() the graphs were captured under
         self._warm = False
         self._out = None
-        self._stage = {}
+        self._pending = []
         if self.bf16:
             self._pack = {k: [torch.empty(hi - lo, dtype=torch.bfloat16, device=engine.device) for lo, hi in v]
                           for k, v in engine.grad_ranges().items()}
@@ -75,30 +75,45 @@ class DataParallelStep:
             broadcast_parameters(engine, 0, group)
 
     # ------------------------------------------------------------------ plan
+    def plan(self):
+        """[(stage name, compute callable, collective callable or None)]: the compute callables only enqueue device work
+        (capturable); a collective is issued by the host after its stage, so it ends a graph segment"""
+        if getattr(self.eng, "shard", None) is not None:
+            return sharded_plan(self)
+        e, multi = self.eng, self.multi
+
+        def upper():
+            self._out = e.stage_upper(self.labels)
+        return [("forward", lambda: e.stage_forward(self.images, self.labels), self._comm_ty if (multi and e.exchange_ty) else None),
+                ("upper", upper, self._comm_upper if multi else None),
+                ("lower", e.stage_lower, self._comm_lower if multi else None),
+                ("update", e.stage_update, None)]
+
+    def _segment_items(self):
+        segs, cur = [], []
+        for item in self.plan():
+            cur.append(item)
+            if item[2] is not None:
+                segs.append(cur)
+                cur = []
+        if cur:
+            segs.append(cur)
+        return segs
+
     def segments(self):
         """stage names grouped into graph segments: a segment ends where the host has to issue a collective"""
-        if not self.multi:
-            return [list(STAGES)]
-        segs = [["forward"], ["upper"]] if self.eng.exchange_ty else [["forward", "upper"]]
-        return segs + [["lower"], ["update"]]
+        return [[name for name, _, _ in items] for items in self._segment_items()]
 
-    def _run_stage(self, name):
-        e = self.eng
-        if name == "forward":
-            e.stage_forward(self.images, self.labels)
-        elif name == "upper":
-            self._out = e.stage_upper(self.labels)
-        elif name == "lower":
-            e.stage_lower()
-        else:
-            e.stage_update()
+    def _comm_ty(self):                     # CurricularFace: global sum of the target cosines (criterion.py:570-573)
+        dist.all_reduce(self.eng.ty_sum, op=dist.ReduceOp.SUM, group=self.group)
 
-    def _run_segment(self, idx, names):
-        if self._graphs is not None:
-            self._graphs[idx].replay()
-        else:
-            for n in names:
-                self._run_stage(n)
+    def _comm_upper(self):                  # starts here, runs under the lower backward
+        self._pending += self._reduce_ranges("upper")
+
+    def _comm_lower(self):
+        self._pending += self._reduce_ranges("lower")
+        self._finish(self._pending)
+        self._pending = []
 
     # ------------------------------------------------------------------ collectives (host-issued, between segments)
     def _reduce_ranges(self, which):
@@ -135,11 +150,11 @@ class DataParallelStep:
     def _capture(self):
         graphs = []
         torch.cuda.synchronize(self.eng.device)
-        for names in self.segments():
+        for items in self._segment_items():
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                for n in names:
-                    self._run_stage(n)
+                for _, fn, _ in items:
+                    fn()
             graphs.append(g)
         self._graphs = graphs
         self._key = self._engine_key()
@@ -166,20 +181,16 @@ class DataParallelStep:
             self._graphs = None        # host-side values baked into the captured launches changed: capture again
         if self.use_graph and self._graphs is None and self._warm:
             self._capture()
-        segs = self.segments()
-        pending = []
-        for idx, names in enumerate(segs):
-            self._run_segment(idx, names)
-            if self.multi:
-                last = names[-1]
-                if last == "forward":                   # CurricularFace: global sum of the target cosines
-                    dist.all_reduce(e.ty_sum, op=dist.ReduceOp.SUM, group=self.group)
-                elif last == "upper":
-                    pending += self._reduce_ranges("upper")        # overlaps the lower backward
-                elif last == "lower":
-                    pending += self._reduce_ranges("lower")
-                    self._finish(pending)
-                    pending = []
+        self._pending = []
+        for idx, items in enumerate(self._segment_items()):
+            if self._graphs is not None:
+                self._graphs[idx].replay()
+            else:
+                for _, fn, _ in items:
+                    fn()
+            comm = items[-1][2]
+            if comm is not None:
+                comm()
         if self._graphs is not None:
             e.post_replay()
         self._warm = True
@@ -188,3 +199,64 @@ class DataParallelStep:
     @property
     def graphed(self):
         return self._graphs is not None
+
+
+def _reduce_scatter_rows(out, full, group):
+    """out [N, D] <- this rank's rows of the SUM over ranks of full [world * N, D]"""
+    try:
+        dist.reduce_scatter_tensor(out, full, op=dist.ReduceOp.SUM, group=group)
+    except (RuntimeError, NotImplementedError):          # backends without reduce-scatter (gloo): all-reduce, keep own rows
+        dist.all_reduce(full, op=dist.ReduceOp.SUM, group=group)
+        r, n = dist.get_rank(group), out.shape[0]
+        out.copy_(full[r * n:(r + 1) * n])
+
+
+def sharded_plan(st):
+    """Step plan for an engine with a CLASS-SHARDED head (engine.shard = (rank, world); SURVEY 8(f)-4, the reference's
+    dormant device_id chunking criterion.py:268-278 with the exchanges it lacks).  Each rank owns C / world class columns:
+      backbone forward (own batch)            [all-gather features + labels: every rank sees the global batch]
+      cosines against the own columns         [all-reduce SUM of the target cosines: the owner of a label fills it in]
+      margin + row sweep over the own columns [all-reduce MAX of the row maxima]
+      rescale the partial sum-exp             [all-reduce SUM of (sum-exp, rank)]
+      loss / top-k, head backward             [reduce-scatter SUM of the partial dL/dfeats: each rank gets its own rows]
+      backbone backward / update exactly as in the replicated-head plan; the head gradient never crosses the wire.
+    The engine supplies the compute stages (shard_stage_*) and the exchange buffers (feats_l/_g, labels_l/_g, ty_g, part,
+    gmax, dx_g, dfeat)."""
+    e, g, multi = st.eng, st.group, st.world > 1
+
+    def gather():
+        if multi:
+            dist.all_gather_into_tensor(e.feats_g, e.feats_l, group=g)
+            dist.all_gather_into_tensor(e.labels_g, e.labels_l, group=g)
+        else:
+            e.feats_g.copy_(e.feats_l)
+            e.labels_g.copy_(e.labels_l)
+
+    def ty():
+        if multi:
+            dist.all_reduce(e.ty_g, op=dist.ReduceOp.SUM, group=g)
+
+    def rmax():
+        if multi:
+            dist.all_reduce(e.gmax, op=dist.ReduceOp.MAX, group=g)
+
+    def rsum():
+        if multi:
+            dist.all_reduce(e.part[1:3], op=dist.ReduceOp.SUM, group=g)
+
+    def scatter():
+        if multi:
+            _reduce_scatter_rows(e.dfeat, e.dx_g, g)
+        else:
+            e.dfeat.copy_(e.dx_g)
+
+    def head_bwd():
+        st._out = e.shard_stage_head_bwd()
+    return [("backbone", lambda: e.shard_stage_backbone(st.images, st.labels), gather),
+            ("head_cos", e.shard_stage_cos, ty),
+            ("head_rows", e.shard_stage_rows, rmax),
+            ("head_rescale", e.shard_stage_rescale, rsum),
+            ("head_bwd", head_bwd, scatter),
+            ("upper", e.shard_stage_upper, st._comm_upper if st.multi else None),
+            ("lower", e.stage_lower, st._comm_lower if st.multi else None),
+            ("update", e.stage_update, None)]

@@ -643,20 +643,47 @@ class FaceEngine:
     """Backbone + margin head + fused SGD: one training step = forward, CE, backward, update."""
 
     def __init__(self, kind, num_classes, batch, dtype=BF16, device="cuda:0", s=None, m=None, momentum=0.01, seed=None,
-                 share=None, head_p=None, head_flags=None, lambda_g=0.0, elastic_std=0.0125):
+                 share=None, head_p=None, head_flags=None, lambda_g=0.0, elastic_std=0.0125, shard=None):
+        """shard = (rank, world): class-sharded head -- this replica owns the class columns
+        [rank * Cs, (rank + 1) * Cs), Cs = ceil(C / world); the batch of all ranks is gathered for the head, no head
+        gradient crosses the wire (frx/ddp.py: sharded_plan).  The backbone stays a plain data-parallel replica."""
         self.kind = HEAD_KINDS[kind] if isinstance(kind, str) else kind
-        self.C, self.N = num_classes, batch
+        self.C_full, self.N = num_classes, batch
+        self.shard = shard
+        if shard is not None:
+            rank, world = shard
+            self.Cs = -(-num_classes // world)
+            self.c0 = rank * self.Cs
+            self.C = min(num_classes, self.c0 + self.Cs) - self.c0
+            if self.C <= 0:
+                raise ValueError(f"class shard {rank} of {world} is empty for {num_classes} classes")
+            self.N_g = batch * world
+        else:
+            self.Cs = self.C = num_classes
+            self.c0, self.N_g = 0, batch
         ds, dm = HEAD_DEFAULTS[self.kind]
         self.s, self.m = (ds if s is None else s), (dm if m is None else m)
         self.w_cd = self.kind in ops.W_CD_KINDS
-        self.net = ResNet50Engine(batch, dtype, device, extra_params=num_classes * FEATURE_DIM,
+        # (every rank reserves Cs columns, so the flat layouts -- and the backbone's all-reduce ranges -- agree across ranks)
+        self.net = ResNet50Engine(batch, dtype, device, extra_params=self.Cs * FEATURE_DIM,
                                   share=None if share is None else share.net)
         self.device = self.net.device
         self.head_p = tuple(HEAD_P_DEFAULTS.get(self.kind, ()) if head_p is None else head_p)
         self.elastic_std = float(elastic_std)
         head_flags = HEAD_FLAG_DEFAULTS.get(self.kind, 0) if head_flags is None else head_flags
-        self.head = ops.HeadContext(self.kind, batch, FEATURE_DIM, num_classes, self.s, self.m, momentum, device=self.device,
-                                    p=self.head_p, flags=head_flags, lambda_g=lambda_g)
+        self.head = ops.HeadContext(self.kind, self.N_g, FEATURE_DIM, self.C, self.s, self.m, momentum, device=self.device,
+                                    p=self.head_p, flags=head_flags, lambda_g=lambda_g,
+                                    class_offset=self.c0 if shard is not None else None)
+        if shard is not None:
+            dev, ng = self.device, self.N_g
+            self.labels_l = torch.zeros(batch, dtype=torch.int64, device=dev)
+            self.feats_g = torch.zeros(ng, FEATURE_DIM, device=dev)       # all-gathered features / labels
+            self.labels_g = torch.zeros(ng, dtype=torch.int64, device=dev)
+            self.ty_g = torch.zeros(ng, device=dev)                       # target cosines (SUM all-reduce)
+            self.part = torch.zeros(3, ng, device=dev)                    # row max | sum-exp | rank over the local columns
+            self.gmax = torch.zeros(ng, device=dev)                       # row max over ALL columns (MAX all-reduce)
+            self.dx_g = torch.zeros(ng, FEATURE_DIM, device=dev)          # this shard's partial dL/dfeats of every row
+            self.gout = torch.full((1,), float(world), device=dev)        # the fused SGD rescales every gradient by 1/world
         # Head state (include/frx.h, `state_t`): CurricularFace's `t` [1] (criterion.py:517); AdaFace's batch_mean /
         # batch_std [2] (:838-839), shared between batch sizes like `t`; the elastic heads' per-row margins [N];
         # VPL-ArcFace's class memory `mem` [C,512] followed by `life` [C] (:660-661), shared as well.
@@ -698,7 +725,7 @@ class FaceEngine:
         g = torch.Generator(device="cpu")
         if seed is not None:
             g.manual_seed(seed + 1)
-        C, D = self.C, FEATURE_DIM
+        C, D = self.C_full, FEATURE_DIM
         if self.kind in (ops.ARC, ops.SPHERE, ops.VPL):      # xavier_uniform_ on [C,D] (criterion.py:244,37,657)
             bound = math.sqrt(6.0 / (C + D))
             w = (torch.rand(C, D, generator=g) * 2 - 1) * bound
@@ -708,7 +735,9 @@ class FaceEngine:
             w = (torch.rand(D, C, generator=g) * 2 - 1).renorm_(2, 1, 1e-5).mul_(1e5)
         else:                                        # normal(std=0.01) (criterion.py:514,973,1080)
             w = torch.randn(D, C, generator=g) * 0.01
-        self.head_w().copy_(w)
+        if self.shard is not None:              # the same full-width draw on every rank, each keeps its own columns
+            w = w[self.c0:self.c0 + self.C] if self.w_cd else w[:, self.c0:self.c0 + self.C]
+        self.head_w().copy_(w.contiguous())
         if self.kind == ops.ADA:
             self.t.copy_(torch.tensor([20.0, 100.0]))
         elif self.kind in ELASTIC_KINDS:
@@ -755,11 +784,19 @@ class FaceEngine:
         return self.net.grads
 
     def grad_ranges(self):
-        return self.net.grad_ranges()
+        r = self.net.grad_ranges()
+        if self.shard is not None:              # the head's columns are this rank's own: their gradient never travels
+            cut = self.net.extra_off
+            r = {k: [(lo, min(hi, cut)) for lo, hi in v if lo < cut] for k, v in r.items()}
+        return r
 
     def replica_state(self):
         """tensors every data-parallel replica must start equal in (broadcast from rank 0)"""
-        return [self.net.params, self.net.mom, self.net.running_mean, self.net.running_var, self.net.num_batches_tracked, self.t]
+        net = self.net
+        if self.shard is not None:              # (not the head columns: every rank initialised its own slice)
+            cut = net.extra_off
+            return [net.params[:cut], net.mom[:cut], net.running_mean, net.running_var, net.num_batches_tracked, self.t]
+        return [net.params, net.mom, net.running_mean, net.running_var, net.num_batches_tracked, self.t]
 
     def after_broadcast(self):
         self.net.sync_weights()
@@ -804,6 +841,48 @@ class FaceEngine:
                           dw=self.head_w(self.net.grads), accumulate_dw=False)
         self.net.backward_upper(self.dfeat)
         return out
+
+    # ---- class-sharded head: the compute between the collectives of frx/ddp.py: sharded_plan
+    def shard_stage_backbone(self, images, labels):
+        self.net.training = True
+        self.net.zero_grad()
+        self.net.forward(images)
+        self.feats_l = self.net.feats
+        self.labels_l.copy_(labels)
+
+    def shard_stage_cos(self):
+        ops.head_shard_cos(self.head, self.feats_g, self.head_w(), self.labels_g, self.ty_g)
+
+    def shard_stage_rows(self):
+        if self.kind == ops.SPHERE:
+            self.head.desc.flags |= 4
+        ops.head_shard_rows(self.head, self.labels_g, self.ty_g, self.part, state_t=self.t)
+        self.gmax.copy_(self.part[0])
+
+    def shard_stage_rescale(self):
+        ops.head_shard_rescale(self.part[0], self.gmax, self.part[1])
+
+    def shard_stage_head_bwd(self):
+        out = ops.head_shard_finish(self.head, self.gmax, self.part[1], self.part[2], state_t=self.t)
+        out["feats"] = self.net.feats
+        self.last = out
+        ops.head_backward(self.head, self.feats_g, self.head_w(), self.labels_g, state_t=self.t, gout=self.gout,
+                          dx=self.dx_g, dw=self.head_w(self.net.grads), accumulate_dw=False)
+        return out
+
+    def shard_stage_upper(self):
+        self.net.backward_upper(self.dfeat)
+
+    def gather_head_weight(self, group=None):
+        """the full [C, 512] / [512, C] head weight assembled from every rank's columns (checkpoints)"""
+        import torch.distributed as dist
+        world = self.shard[1]
+        mine = torch.zeros(self.Cs, FEATURE_DIM, device=self.device)
+        mine[:self.C] = self.head_w() if self.w_cd else self.head_w().t()
+        full = torch.empty(world * self.Cs, FEATURE_DIM, device=self.device)
+        dist.all_gather_into_tensor(full, mine, group=group)
+        full = full[:self.C_full]
+        return full.contiguous() if self.w_cd else full.t().contiguous()
 
     def stage_lower(self):
         self.net.backward_lower()

@@ -75,13 +75,18 @@ def _chk(t, dtype, name):
 class HeadContext:
     """Descriptor + workspace of one head instance (one per model; reused every step)."""
 
-    def __init__(self, kind, N, D, C_, s, m, momentum=0.01, device=None, p=(0.0, 0.0, 0.0, 0.0), flags=0, lambda_g=0.0):
+    def __init__(self, kind, N, D, C_, s, m, momentum=0.01, device=None, p=(0.0, 0.0, 0.0, 0.0), flags=0, lambda_g=0.0,
+                 class_offset=None):
         """p / flags: per-kind parameters of frx_head_desc (MV: mv_weight; ADA: h, t_alpha; MAG: l_margin, u_margin,
         l_a, u_a and flags bit 0 = easy_margin; VPL: lamda, delta and flags bit 0 = easy_margin, bit 1 = memory in use).
-        lambda_g: MagFace's loss_g weight for the fused backward."""
+        lambda_g: MagFace's loss_g weight for the fused backward.
+        class_offset: not None = class-sharded mode: this context is the column shard [class_offset, class_offset + C_)
+        of a wider head and N counts the rows of the gathered batch (head_shard_* below)."""
         p = tuple(float(v) for v in p) + (0.0,) * (4 - len(p))
+        if class_offset is not None:
+            flags = int(flags) | 8
         self.desc = HeadDesc(kind, N, D, C_, s, m, momentum, float(lambda_g) if kind == MAG else 0.0,
-                             (C.c_float * 4)(*p), int(flags), 0)
+                             (C.c_float * 4)(*p), int(flags), int(class_offset or 0))
         nbytes = _lib.lib().frx_head_workspace_bytes(C.byref(self.desc))
         if nbytes == 0:
             raise FrxError("head descriptor rejected: " + _lib.lib().frx_last_error().decode())
@@ -152,6 +157,45 @@ def head_forward(ctx: HeadContext, x, w, labels, state_t=None, lamb=0.0, want_lo
     tys = head_forward_cos(ctx, x, w, labels, state_t)
     count = ctx.desc.N if ty_allreduce is None else ty_allreduce(tys)
     return head_forward_loss(ctx, labels, tys, count, state_t, lamb, want_logits)
+
+
+# ---- class-sharded head: the four compute phases between the caller's collectives (include/frx.h)
+def head_shard_cos(ctx: HeadContext, x, w, labels, ty_out):
+    N, D, Cc = ctx.shape
+    _chk(x, torch.float32, "x"); _chk(w, torch.float32, "w"); _chk(labels, torch.int64, "labels"); _chk(ty_out, torch.float32, "ty_out")
+    if tuple(x.shape) != (N, D) or labels.numel() != N or w.numel() != D * Cc or ty_out.numel() != N:
+        raise FrxError(f"head_shard_cos: shapes x{tuple(x.shape)} w{tuple(w.shape)} labels{tuple(labels.shape)} "
+                       f"do not match the context (N={N}, D={D}, C={Cc})")
+    check(_lib.lib().frx_head_shard_cos(_dev(x), _stream(x), C.byref(ctx.desc), _p(x), _p(w), _p(labels), _p(ctx.ws),
+                                        ctx.nbytes, _p(ty_out)), "frx_head_shard_cos")
+    return ty_out
+
+
+def head_shard_rows(ctx: HeadContext, labels, ty_global, part, state_t=None):
+    """part [3, N] <- (row max, sum exp(z - row max), local rank count) over this shard's columns"""
+    N = ctx.shape[0]
+    _chk(part, torch.float32, "part"); _chk(ty_global, torch.float32, "ty_global")
+    if part.numel() != 3 * N or ty_global.numel() != N:
+        raise FrxError("head_shard_rows: part must hold 3*N floats and ty_global N")
+    check(_lib.lib().frx_head_shard_rows(_dev(part), _stream(part), C.byref(ctx.desc), _p(labels), _p(state_t), _p(ty_global),
+                                         _p(ctx.ws), ctx.nbytes, _p(part)), "frx_head_shard_rows")
+    return part
+
+
+def head_shard_rescale(local_max, global_max, part_sum):
+    check(_lib.lib().frx_head_shard_rescale(_dev(part_sum), _stream(part_sum), part_sum.numel(), _p(local_max), _p(global_max),
+                                            _p(part_sum)), "frx_head_shard_rescale")
+
+
+def head_shard_finish(ctx: HeadContext, global_max, global_sum, global_rank, state_t=None):
+    N = ctx.shape[0]
+    dev = global_max.device
+    o = dict(loss=torch.empty(1, device=dev), topk=torch.empty(2, dtype=torch.int32, device=dev),
+             norms=torch.empty(N, device=dev), lse=torch.empty(N, device=dev), cos_s=None, logits=None)
+    check(_lib.lib().frx_head_shard_finish(_dev(global_max), _stream(global_max), C.byref(ctx.desc), _p(state_t), _p(global_max),
+                                           _p(global_sum), _p(global_rank), _p(ctx.ws), ctx.nbytes, _p(o["norms"]), _p(o["loss"]),
+                                           _p(o["lse"]), _p(o["topk"])), "frx_head_shard_finish")
+    return o
 
 
 def head_backward(ctx: HeadContext, x, w, labels, state_t=None, gout=None, dx=None, dw=None, accumulate_dw=False):

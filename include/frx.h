@@ -77,8 +77,11 @@ typedef struct frx_head_desc {
   int32_t flags;     /* MAG, VPL: bit 0 = easy_margin (criterion.py:1187, 631)
                         VPL: bit 1 = norm_training_flag, the memory is in use (criterion.py:671-679)
                         SPHERE: bit 2 = read the annealing lambda from state_t[0] instead of `lamb` (a captured
-                                hipGraph then follows criterion.py:58-60 without re-capture) */
-  int32_t reserved;
+                                hipGraph then follows criterion.py:58-60 without re-capture)
+                        bit 3 = class-sharded mode (ARC / COS / SPHERE / CURR / MV_*): this descriptor is the column
+                                shard [class_offset, class_offset + C) of a wider head; N counts the rows of the
+                                GATHERED batch and labels stay global (see "class-sharded head" below) */
+  int32_t class_offset; /* flags bit 3: global index of the shard's first class; otherwise ignored */
 } frx_head_desc;
 
 /* Per-kind meaning of the `state_t` argument of the calls below (device floats owned by the caller):
@@ -114,6 +117,28 @@ int frx_head_fwd_loss(int device, frx_stream_t stream, const frx_head_desc* d, c
  * memory and the lamda blend of criterion.py:699-722 written over the cosines in the workspace (flags bit 1 clear: no-op). */
 int frx_head_vpl_prepare(int device, frx_stream_t stream, const frx_head_desc* d, const float* x, const int64_t* labels,
                          float* state_t, void* ws, size_t ws_bytes);
+/* ---- class-sharded head (the reference's dormant device_id chunking, criterion.py:268-278, is the same
+ * partition without the exchanges).  Each rank owns C/world class columns (no head gradient on the wire); the batch is
+ * all-gathered, so N = world x per-rank batch rows.  Sequence per step, collectives issued by the caller in between:
+ *   frx_head_shard_cos    -> ty_out [N]: clamped target cosine of the rows whose label falls in this shard, 0 elsewhere
+ *     [all-reduce SUM of ty_out over ranks -> every rank holds every row's target cosine]
+ *   frx_head_shard_rows   (state update from the global target cosines, margin + row sweep over the local columns)
+ *                         -> part [3][N]: row max, sum exp(z - row max), count of local columns ranked above the target
+ *     [all-reduce MAX of a copy of part[0] -> global_max]
+ *   frx_head_shard_rescale  part[1][n] *= exp(part[0][n] - global_max[n])
+ *     [all-reduce SUM of part[1..2] -> global sum-exp and global rank]
+ *   frx_head_shard_finish -> loss, lse, top-k (identical on every rank); the global lse stays in the workspace
+ *   frx_head_bwd          -> dw of the LOCAL columns (complete) and this shard's PARTIAL dx [N, D]
+ *     [reduce-scatter SUM of dx -> each rank's own rows]; pass gout = world when the optimiser rescales by 1/world */
+int frx_head_shard_cos(int device, frx_stream_t stream, const frx_head_desc* d, const float* x, const float* w,
+                       const int64_t* labels, void* ws, size_t ws_bytes, float* ty_out);
+int frx_head_shard_rows(int device, frx_stream_t stream, const frx_head_desc* d, const int64_t* labels, float* state_t,
+                        const float* ty_global, void* ws, size_t ws_bytes, float* part);
+int frx_head_shard_rescale(int device, frx_stream_t stream, int N, const float* local_max, const float* global_max,
+                           float* part_sum);
+int frx_head_shard_finish(int device, frx_stream_t stream, const frx_head_desc* d, const float* state_t,
+                          const float* global_max, const float* global_sum, const float* global_rank, void* ws,
+                          size_t ws_bytes, float* norms, float* loss, float* lse, int32_t* topk);
 /* After frx_head_fwd_loss: loss_g [1] (MAG: mean(x_norm / u_a^2 + 1 / x_norm), criterion.py:1235-1239; 0 for other
  * kinds) and, optionally, the per-row parameter the epilogue used, row_param [N]: ADA margin_scaler (:879-880), MAG
  * ada_margin (:1229-1233), ELASTIC_* the margins passed in; zeros otherwise.  For MAG the `norms` output of
