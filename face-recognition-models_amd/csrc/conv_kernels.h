@@ -416,15 +416,16 @@ __global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN 
 #pragma unroll
     for (int ks = 0; ks < KC / 64; ++ks) {             // one MFMA k-step = 64 bytes of the contraction axis
       uint4 fa[FM], fb[FN];
-#pragma unroll
-      for (int i = 0; i < FM; ++i) {
-        const int row = wm * WTM + i * 16 + fr;
-        fa[i] = *reinterpret_cast<const uint4*>(As + (row * CPR + ((ks * 4 + fq) ^ swz_row<KC>(row))) * 16);
-      }
+      // (weight fragments first: LDS returns reads in issue order, and the first MFMAs need fb[0..] and fa[0] only)
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         const int row = wn * WTN + chan_of(j, fr);
         fb[j] = *reinterpret_cast<const uint4*>(Bs + (row * CPR + ((ks * 4 + fq) ^ swz_row<KC>(row))) * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int row = wm * WTM + i * 16 + fr;
+        fa[i] = *reinterpret_cast<const uint4*>(As + (row * CPR + ((ks * 4 + fq) ^ swz_row<KC>(row))) * 16);
       }
       // Operands are swapped (weights first): D[row = channel][col = pixel], so a lane ends up with
       // 4 CONSECUTIVE channels of one pixel per fragment -- contiguous in NHWC memory.

@@ -64,4 +64,27 @@ out["lfw6000_result"] = [round(v, 4) for v in res]
 from oracle import verify as OV
 (ma, sa, mu, su), _, _ = OV.cross_validate_kfold(cos.cpu().numpy(), same, 10)
 out["lfw6000_oracle_protocol_acc"] = round(ma, 4)
+# ---- (3) the drop-in loop a user of arcface.py gets: utils.model_utils.train_model on ArcFaceNet with FusedSGD (hipGraph replay
+# from the second step on, copy-stream prefetch), fed uint8 HWC batches and, separately, the reference's fp32 CHW batches
+del eng
+import types, torch.nn as nn
+from utils import criterion as UC
+for mode in ("uint8", "fp32"):
+    torch.manual_seed(0)
+    model = UC.ArcFaceNet(num_classes=C, backbone="resnet50").to(dev)
+    opt = MU.make_optimizer(model, 0.005)
+    if mode == "uint8":
+        data = [(host[i % 4], lab.cpu()) for i in range(44)]
+    else:
+        f = [((h.permute(0, 3, 1, 2).float() / 255.0 - 0.5) / 0.5).contiguous().pin_memory() for h in host]
+        data = [(f[i % 4], lab.cpu()) for i in range(44)]
+    args = types.SimpleNamespace(lambda_g=0.0, print_freq=1000)
+    crit = nn.CrossEntropyLoss().to(dev)
+    with contextlib.redirect_stdout(io.StringIO()):
+        MU.train_model(model, data[:4], crit, opt, MU.GradScaler(enabled=False), dev, 1, 1, args)      # engine build, eager step, capture
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        MU.train_model(model, data[4:], crit, opt, MU.GradScaler(enabled=False), dev, 1, 1, args)
+        torch.cuda.synchronize(); dt = time.perf_counter() - t0
+    out[f"train_model_dropin_{mode}_img_per_s"] = round(N * 40 / dt, 1)
+    del model, opt
 print(json.dumps(out))

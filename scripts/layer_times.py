@@ -9,17 +9,20 @@ eng = E.FaceEngine("arcface", 10575, N, dtype=ops.BF16, device="cuda:0", seed=0)
 g = torch.Generator().manual_seed(0)
 images = (torch.rand(N, 3, 112, 112, generator=g) * 2 - 1).cuda(); labels = torch.randint(0, 10575, (N,), generator=g).cuda()
 # wrap to capture descriptors
-calls = []
+descs = []
+cur = [None]
 orig = ops._timed
 def timed(label, flops, t, fn, nbytes=0):
-    calls.append(label); return orig(label, flops, t, fn, nbytes)
+    if ops.PROFILER is not None:
+        descs.append(cur[0])            # one entry per profiled launch (None: the grouped weight-gradient launch)
+    cur[0] = None
+    return orig(label, flops, t, fn, nbytes)
 ops._timed = timed
-descs = []
 for name in ("conv_fwd", "conv_dgrad", "conv_wgrad", "conv_dgrad_bn", "conv_wgrad_bn"):
     f = getattr(ops, name)
     def mk(f, name):
         def w(d, *a, **k):
-            descs.append((name, d)); return f(d, *a, **k)
+            cur[0] = (name, d); return f(d, *a, **k)
         return w
     setattr(ops, name, mk(f, name))
 eng.train_step(images, labels, 0.1); eng.train_step(images, labels, 0.1)
@@ -35,7 +38,13 @@ for _ in range(REP):
 rec = ops.PROFILER; ops.PROFILER = None
 tot = {}
 print(f"{'op':11s} {'kernel':24s} {'Ci':>5s} {'Co':>5s} k s {'Hi':>3s} {'us':>8s} {'TF/s':>7s} {'GB/s':>7s}")
-for (name, d), (label, flops, _, _, nb), us in zip(descs, rec, acc):
+assert len(descs) == len(rec), (len(descs), len(rec))
+for nd, (label, flops, _, _, nb), us in zip(descs, rec, acc):
+    if nd is None:
+        print(f"{'wgrad_group':11s} {label:24s} {'':5s} {'':5s}     {'':3s} {us:8.1f} {flops/us/1e6:7.1f} {nb/us/1e3:7.0f}")
+        tot['wgrad_group'] = tot.get('wgrad_group', 0) + us
+        continue
+    name, d = nd
     M_out = d.N * d.Ho * d.Wo; M_in = d.N * d.Hi * d.Wi
     byt = nb or 2 * (M_in * (4 if d.stem else d.Ci) + M_out * d.Co + d.Co * d.R * d.S * d.Ci)
     print(f"{name:11s} {label:24s} {d.Ci:5d} {d.Co:5d} {d.R} {d.stride} {d.Hi:3d} {us:8.1f} {flops/us/1e6:7.1f} {byt/us/1e3:7.0f}")

@@ -15,6 +15,9 @@ SHAPES = [
     (128, 128, 3, 2, 28), (256, 512, 1, 2, 28), (512, 128, 1, 1, 14), (128, 128, 3, 1, 14),
     (256, 256, 3, 2, 14), (1024, 256, 1, 1, 7), (256, 256, 3, 1, 7), (512, 512, 3, 2, 7),
     (2048, 512, 1, 1, 4), (512, 512, 3, 1, 4), (512, 2048, 1, 1, 4),
+    # the remaining Appendix-A shapes (these were reached only through the whole-net test)
+    (256, 128, 1, 1, 28), (128, 512, 1, 1, 14), (512, 256, 1, 1, 14), (256, 1024, 1, 1, 7), (512, 1024, 1, 2, 14),
+    (1024, 512, 1, 1, 7), (1024, 2048, 1, 2, 7),
 ]
 
 

@@ -94,7 +94,7 @@ def test_head_vs_oracle_seeded(name, shape):
         assert t_after == pytest.approx(st.t, abs=1e-6)
 
 
-@pytest.mark.parametrize("name,N,Cc", [("arcface", 256, 10575), ("curricular", 128, 85000)])
+@pytest.mark.parametrize("name,N,Cc", [("arcface", 256, 10575), ("cosface", 256, 10575), ("curricular", 128, 85000)])
 def test_head_full_size_properties(name, N, Cc):
     """BASELINE sizes: size-independent properties instead of an O(N*C*D) oracle run:
     softmax rows sum to 1 (via lse), loss == mean(lse - z_y), rows of dC sum to ~0 for the

@@ -150,7 +150,7 @@ def test_state_is_required():
         ops.HeadContext(H.MAG, 8, 64, 10, 64.0, 0.0, device=dev, p=(0.45, 0.8, 110.0, 10.0))   # l_a > u_a
 
 
-@pytest.mark.parametrize("name", ["mv_arc", "adaface", "elastic_arc", "magface", "vpl_arcface"])
+@pytest.mark.parametrize("name", ["mv_am", "mv_arc", "adaface", "elastic_arc", "elastic_cos", "magface", "vpl_arcface"])
 def test_head_full_size_properties(name):
     """BASELINE head size (N=256, C=10575, D=512): size-independent properties instead of an O(N*C*D) oracle run --
     lse is the log-sum-exp of the returned logits, loss == mean(lse - z_y), non-target logits are s*cos except where the
@@ -171,7 +171,7 @@ def test_head_full_size_properties(name):
     st = None
     if kind == H.ADA:
         st = torch.tensor([20.0, 100.0], device=dev)
-    elif kind == H.ELASTIC_ARC:
+    elif kind in (H.ELASTIC_ARC, H.ELASTIC_COS):
         st = torch.empty(N, device=dev).normal_(hy.m, 0.0125).clamp_(hy.m - 0.0125, hy.m + 0.0125)
     elif kind == H.VPL:
         st = torch.zeros(Cc * D + Cc, device=dev)
@@ -182,7 +182,7 @@ def test_head_full_size_properties(name):
     np.testing.assert_allclose(o["lse"].cpu().numpy(), lse.numpy(), atol=1e-3)
     assert abs(o["loss"].item() - (lse - z[torch.arange(N), y]).mean().item()) < 1e-3
     cs = o["cos_s"].cpu()
-    if kind not in (H.MV_ARC, H.VPL):
+    if kind not in (H.MV_AM, H.MV_ARC, H.VPL):
         nt = torch.ones(N, Cc, dtype=torch.bool)
         nt[torch.arange(N), y] = False
         assert (o["logits"].cpu()[nt] - cs[nt]).abs().max().item() < 1e-3
@@ -197,7 +197,7 @@ def test_head_full_size_properties(name):
     assert int(hit[:, :1].sum()) == int(o["topk"][0]) and int(hit.sum()) == int(o["topk"][1])
     dx, dw = ops.head_backward(ctx, xd, wd, yd, state_t=st)
     assert torch.isfinite(dx).all() and torch.isfinite(dw).all() and dx.abs().max().item() > 0
-    if kind in (H.MV_ARC, H.ELASTIC_ARC, H.VPL):      # scale-invariant in x: d/ds L(s*x) = 0
+    if kind in (H.MV_AM, H.MV_ARC, H.ELASTIC_ARC, H.ELASTIC_COS, H.VPL):      # scale-invariant in x: d/ds L(s*x) = 0
         rad = (dx.cpu() * x).sum(1).abs().max().item()
         assert rad < 1e-4 * dx.abs().max().item() * x.norm(dim=1).max().item() + 1e-6
     if kind == H.VPL:
