@@ -20,6 +20,11 @@ static int launch_igemm(hipStream_t st, ConvArgs a, int dtype) {
   a.xbytes = (unsigned)xb; a.wbytes = (unsigned)wb;
   TileCfg c = pick_tile(a.M, a.Ncol, a.mode == MODE_STEM, a.mode != MODE_DGRAD);
   if (a.Ncol % c.bn != 0) c = TileCfg{c.bm, 64, 4, 64};
+  // conv1-type input gradients (narrow contraction, three full-width tensors in the epilogue: addend, masked BN input,
+  // output): the 128x64 four-wave tile -- twice the blocks, three resident per CU -- interleaves the epilogues' memory
+  // phases better than two eight-wave blocks (scripts/fused_ab.py on HBM-resident data: 130 -> 107 us at 56x56,
+  // 76 -> 61 us at 28x28, 55 -> 49 us at 14x14)
+  if (a.mode == MODE_DGRAD && a.epi_bnbwd && a.addend && c.bm == 128 && c.bn == 128 && !getenv("FRX_IGEMM_TILE")) c = TileCfg{128, 64, 4, 64};
   FRX_CHECK_ARG(c.kc == 64 || (a.Kc * (int)esz) % c.kc == 0, "igemm: %d channels do not fill %d-byte K-chunks", a.Kc, c.kc);
   a.tilesM = cdiv(a.M, c.bm);
   a.tilesN = cdiv(a.Ncol, c.bn);
