@@ -248,12 +248,13 @@ __device__ __forceinline__ void head_z(float cc, bool target, const HeadConst& h
     if (target) {
       const float q = 1.f - cc * cc;
       const float sine = sqrtf(fminf(fmaxf(q, 1e-9f), 1.f));
-      if (cc > h.th) {
+      const bool easy = (h.flags & 1) != 0;                    // easy_margin (criterion.py:284-285): margin only where cos > 0
+      if (easy ? cc > 0.f : cc > h.th) {
         z = (cc * h.cos_m - sine * h.sin_m) * h.s;
         const bool inside = q >= 1e-9f && q <= 1.f;
         dzdc = h.s * (h.cos_m + (inside ? h.sin_m * cc / sine : 0.f));
       } else {
-        z = (cc - h.mm) * h.s;
+        z = (easy ? cc : cc - h.mm) * h.s;
         dzdc = h.s;
       }
     } else {
@@ -265,12 +266,21 @@ __device__ __forceinline__ void head_z(float cc, bool target, const HeadConst& h
     dzdc = h.s;
   } else if (KIND == FRX_SPHERE) {
     if (target) {
+      // cos(m theta) as the Chebyshev polynomial T_m(c) (criterion.py:40-47), its derivative m U_{m-1}(c); m = 1..5
+      const int mi = (int)(h.m + 0.5f);
+      const float c2 = cc * cc;
+      float tm, dtm;
+      if (mi == 1) { tm = cc; dtm = 1.f; }
+      else if (mi == 2) { tm = 2.f * c2 - 1.f; dtm = 4.f * cc; }
+      else if (mi == 3) { tm = (4.f * c2 - 3.f) * cc; dtm = 12.f * c2 - 3.f; }
+      else if (mi == 4) { tm = (8.f * c2 - 8.f) * c2 + 1.f; dtm = (32.f * c2 - 16.f) * cc; }
+      else { tm = ((16.f * c2 - 20.f) * c2 + 5.f) * cc; dtm = (80.f * c2 - 60.f) * c2 + 5.f; }
       const float theta = acosf(cc);
-      const float k = floorf(2.f * theta / 3.14159265358979323846f);
+      const float k = floorf((float)mi * theta / 3.14159265358979323846f);
       const float sign = (((int)k) & 1) ? -1.f : 1.f;
-      const float phi = sign * (2.f * cc * cc - 1.f) - 2.f * k;
+      const float phi = sign * tm - 2.f * k;
       u = (phi - cc) / (1.f + h.lamb) + cc;
-      dzdc = (1.f + (sign * 4.f * cc - 1.f) / (1.f + h.lamb)) * r.xnorm;
+      dzdc = (1.f + (sign * dtm - 1.f) / (1.f + h.lamb)) * r.xnorm;
     } else {
       u = cc;
       dzdc = r.xnorm;
@@ -884,7 +894,8 @@ static int check_desc(const frx_head_desc* d) {
   FRX_CHECK_ARG(d->kind >= FRX_ARC && d->kind <= FRX_VPL, "unknown head kind %d", d->kind);
   FRX_CHECK_ARG(d->N > 0 && d->C > 0 && d->D > 0, "head dims must be positive (N=%d D=%d C=%d)", d->N, d->D, d->C);
   FRX_CHECK_ARG(d->D % 16 == 0, "head feature dim D=%d must be a multiple of 16", d->D);
-  FRX_CHECK_ARG(d->kind != FRX_SPHERE || d->m == 2.f, "SphereFace supports m=2 only (config.py:17), got %g", (double)d->m);
+  FRX_CHECK_ARG(d->kind != FRX_SPHERE || (d->m == 1.f || d->m == 2.f || d->m == 3.f || d->m == 4.f || d->m == 5.f),
+                "SphereFace's margin is an integer 1..5 (the Chebyshev table of criterion.py:40-47), got %g", (double)d->m);
   FRX_CHECK_ARG(d->kind != FRX_MAG || (d->p[3] > d->p[2] && d->p[2] > 0.f), "MagFace needs 0 < l_a < u_a (got %g, %g)",
                 (double)d->p[2], (double)d->p[3]);
   FRX_CHECK_ARG(d->kind != FRX_ADA || d->N > 1, "AdaFace's batch std needs N > 1");

@@ -33,16 +33,16 @@ class _HeadBase(nn.Module):
 
 
 class SphereFace(_HeadBase):
-    """criterion.py:12-107.  m=2 only (config.py:17); `iter` is a Python int as upstream (:33), so it is not
-    part of the state dict and restarts on resume."""
+    """criterion.py:12-107.  m = 1..5 (the Chebyshev table :40-47; config.py:17 ships 2); `iter` is a Python int as
+    upstream (:33), so it is not part of the state dict and restarts on resume."""
     kind = ops.SPHERE
 
     def __init__(self, in_features, out_features, device_id=None, m=4):
         super().__init__()
         if device_id is not None:
             raise NotImplementedError("the reference's dormant model-parallel branch (device_id) is not supported")
-        if int(m) != 2:
-            raise NotImplementedError("native SphereFace implements m=2 (utils.config.M_sphere)")
+        if int(m) not in (1, 2, 3, 4, 5):
+            raise ValueError(f"SphereFace margin m={m}: the Chebyshev table (criterion.py:40-47) holds m = 0..5, and m = 0 is no margin")
         self.in_features, self.num_classes, self.out_features = in_features, out_features, out_features
         self.m, self.s, self.device_id = int(m), 1.0, None
         self.base, self.gamma, self.power, self.LambdaMin, self.iter, self.lamb = 1000.0, 0.12, 1, 5.0, 0, 0.0
@@ -69,18 +69,17 @@ class CosFace(_HeadBase):
 
 
 class ArcFace(_HeadBase):
-    """criterion.py:232-301; parameter `weight` is [C, D]; only easy_margin=False (what ArcFaceNet passes,
-    :313) has a native epilogue."""
+    """criterion.py:232-301; parameter `weight` is [C, D]; easy_margin (:284-285) is a flag of the native epilogue
+    (ArcFaceNet passes False, :313)."""
     kind = ops.ARC
 
     def __init__(self, embed_size, num_classes, device_id=None, s=64.0, m=0.50, easy_margin=True):
         super().__init__()
         if device_id is not None:
             raise NotImplementedError("the reference's dormant model-parallel branch (device_id) is not supported")
-        if easy_margin:
-            raise NotImplementedError("native ArcFace implements easy_margin=False (as ArcFaceNet constructs it)")
         self.in_features, self.out_features, self.num_classes = embed_size, num_classes, num_classes
-        self.s, self.m, self.easy_margin, self.device_id = s, m, False, None
+        self.s, self.m, self.easy_margin, self.device_id = s, m, bool(easy_margin), None
+        self.frx_flags = 1 if easy_margin else 0
         self.weight = nn.Parameter(torch.empty(num_classes, embed_size))
         nn.init.xavier_uniform_(self.weight)
         self.cos_m, self.sin_m = math.cos(m), math.sin(m)

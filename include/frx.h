@@ -65,7 +65,7 @@ int frx_device_props(int device, int64_t props[8]);
 typedef struct frx_head_desc {
   int32_t kind;      /* frx_head_kind */
   int32_t N, D, C;   /* D % 16 == 0 */
-  float s, m;        /* scale / margin (config.py:16-70); SPHERE ignores s, m must be 2; ELASTIC / MAG ignore m */
+  float s, m;        /* scale / margin (config.py:16-70); SPHERE ignores s, m is an integer 1..5; ELASTIC / MAG ignore m */
   float momentum;    /* CURR EMA momentum (config.py:37) */
   float lamb;        /* SPHERE: annealing lambda for THIS forward (criterion.py:58-60; host state)
                         MAG:    frx_head_bwd: lambda_g, the weight of loss_g in the total loss (model_utils.py:180);
@@ -74,7 +74,7 @@ typedef struct frx_head_desc {
                         ADA:  p[0] = h, p[1] = t_alpha (criterion.py:805-807)
                         MAG:  p[0] = l_margin, p[1] = u_margin, p[2] = l_a, p[3] = u_a (criterion.py:1188-1191)
                         VPL:  p[0] = lamda, p[1] = delta (criterion.py:632-633) */
-  int32_t flags;     /* MAG, VPL: bit 0 = easy_margin (criterion.py:1187, 631)
+  int32_t flags;     /* ARC, MAG, VPL: bit 0 = easy_margin (criterion.py:284-285, 1187, 631)
                         VPL: bit 1 = norm_training_flag, the memory is in use (criterion.py:671-679)
                         SPHERE: bit 2 = read the annealing lambda from state_t[0] instead of `lamb` (a captured
                                 hipGraph then follows criterion.py:58-60 without re-capture)

@@ -153,11 +153,12 @@ def head_forward_backward(kind, x, w, labels, hyper: HeadHyper, state: HeadState
         q = dt(1.0) - c * c
         sine = np.sqrt(np.clip(q, dt(1e-9), dt(1.0)))              # :281
         phi = c * cos_m - sine * sin_m                             # :282
-        phi = np.where(c > th, phi, c - mm)                        # :287 (easy_margin=False)
+        on = (c > dt(0)) if hyper.easy_margin else (c > th)
+        phi = np.where(on, phi, c if hyper.easy_margin else c - mm)  # :284-287
         z = (onehot * phi + (dt(1.0) - onehot) * c) * dt(hyper.s)  # :294-295
         cos_s = c * dt(hyper.s)
         inside = (q >= dt(1e-9)) & (q <= dt(1.0))                  # clamp passes grad inclusively
-        dphi = np.where(c > th, cos_m + np.where(inside, sin_m * c / sine, dt(0)), dt(1.0))
+        dphi = np.where(on, cos_m + np.where(inside, sin_m * c / sine, dt(0)), dt(1.0))
         dzdc = dt(hyper.s) * np.where(onehot > 0, dphi, dt(1.0))
         pass_clamp = np.ones_like(c, dtype=bool)
     elif kind == COS:
@@ -174,9 +175,14 @@ def head_forward_backward(kind, x, w, labels, hyper: HeadHyper, state: HeadState
                          hyper.base * (1 + hyper.gamma * state.iter) ** (-hyper.power))  # :60
         lam = dt(state.lamb)
         m = int(hyper.m)
-        assert m == 2, "only m=2 (config.py:17) is on the hot path"
+        assert 1 <= m <= 5, "the Chebyshev table (criterion.py:40-47) covers m = 0..5"
         c = np.clip(c_raw, dt(-1), dt(1))                          # :81
-        cos_m_theta = dt(2) * c * c - dt(1)                        # mlambda[2], :44
+        c2 = c * c
+        cheb = {1: (c, np.ones_like(c)), 2: (dt(2) * c2 - dt(1), dt(4) * c),
+                3: ((dt(4) * c2 - dt(3)) * c, dt(12) * c2 - dt(3)),
+                4: ((dt(8) * c2 - dt(8)) * c2 + dt(1), (dt(32) * c2 - dt(16)) * c),
+                5: (((dt(16) * c2 - dt(20)) * c2 + dt(5)) * c, (dt(80) * c2 - dt(60)) * c2 + dt(5))}
+        cos_m_theta, dcheb = cheb[m]                               # mlambda[m], :40-47, and its derivative
         theta = np.arccos(c)                                       # :88 (detached)
         k = np.floor(dt(m) * theta / dt(math.pi))                  # :89
         sign = np.where(np.mod(k, 2) == 0, dt(1), dt(-1))
@@ -185,7 +191,7 @@ def head_forward_backward(kind, x, w, labels, hyper: HeadHyper, state: HeadState
         z = u * xnorm                                              # :105
         cos_s = c * xnorm
         pass_clamp = (c_raw >= dt(-1)) & (c_raw <= dt(1))
-        dudc = dt(1) + onehot * (sign * dt(4) * c - dt(1)) / (dt(1) + lam)
+        dudc = dt(1) + onehot * (sign * dcheb - dt(1)) / (dt(1) + lam)
         dzdc = dudc * xnorm
         dnorm_coef = u                                             # dz/d||x|| = u
         extra.update(lamb=state.lamb, iter=state.iter)

@@ -64,6 +64,10 @@ def main():
         with contextlib.redirect_stdout(None):
             if kind == "arcface":
                 return RC.ArcFace(D, C, s=64.0, m=0.5, easy_margin=False), "weight"
+            if kind == "arcface_easy":
+                return RC.ArcFace(D, C, s=64.0, m=0.5, easy_margin=True), "weight"
+            if kind == "sphereface_m4":
+                return RC.SphereFace(D, C, m=4), "weight"
             if kind == "cosface":
                 return RC.CosFace(D, C, s=64.0, m=0.35), "kernel"
             if kind == "sphereface":
@@ -86,8 +90,8 @@ def main():
         x[12] = 5.0 * wn[(y[12] + 1) % C] + 0.3 * wn[y[12]]   # a non-target far above the target
         return x.contiguous(), y
 
-    for kind in ["arcface", "cosface", "sphereface", "curricular"]:
-        torch.manual_seed({"arcface": 1, "cosface": 2, "sphereface": 3, "curricular": 4}[kind])
+    for kind in ["arcface", "cosface", "sphereface", "curricular", "arcface_easy", "sphereface_m4"]:
+        torch.manual_seed({"arcface": 1, "cosface": 2, "sphereface": 3, "curricular": 4, "arcface_easy": 5, "sphereface_m4": 6}[kind])
         head, pname = make_head(kind)
         head.train()
         out = {}

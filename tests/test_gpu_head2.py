@@ -3,6 +3,8 @@ HIP forward + CE + loss_g + backward through the C ABI, against the reference's 
 (tests/golden/make_golden_heads2.py) and against the float64 oracle on seeded / ragged shapes."""
 import os
 
+import zlib
+
 import numpy as np
 import pytest
 import torch
@@ -98,7 +100,7 @@ def test_head_vs_oracle_seeded(name, shape):
     """Config-1 head shape (N=32, C=100) plus ragged shapes (odd C, N not a tile multiple); float64 oracle."""
     kind = CASES[name]
     N, D, Cc = shape
-    rng = np.random.RandomState(abs(hash((name, shape))) % 2**31)
+    rng = np.random.RandomState(zlib.crc32(repr((name, shape)).encode()) % 2**31)      # (hash() of a str is salted per process)
     wshape = (Cc, D) if H.weight_is_cd(kind) else (D, Cc)
     w = (rng.randn(*wshape) * 0.05).astype(np.float32)
     y = rng.randint(0, Cc, N)

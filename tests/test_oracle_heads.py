@@ -8,7 +8,18 @@ import pytest
 
 from oracle import heads as H
 
-KINDS = {"arcface": H.ARC, "cosface": H.COS, "sphereface": H.SPHERE, "curricular": H.CURR}
+KINDS = {"arcface": H.ARC, "cosface": H.COS, "sphereface": H.SPHERE, "curricular": H.CURR,
+         "arcface_easy": H.ARC, "sphereface_m4": H.SPHERE}      # (two more constructor variants of the same heads)
+
+
+def hyper_for(name):
+    """the reference constructor arguments behind each fixture (tests/golden/make_golden.py)"""
+    hy = H.HeadHyper.default(KINDS[name])
+    if name == "arcface_easy":
+        hy.easy_margin = True                    # ArcFace(easy_margin=True): criterion.py:284-285
+    if name == "sphereface_m4":
+        hy.m = 4                                 # SphereFace's own default m (criterion.py:17); config.py:17 ships 2
+    return hy
 
 
 def _load(golden_dir, name):
@@ -22,7 +33,7 @@ def test_head_matches_reference(golden_dir, name, tag):
     kind = KINDS[name]
     st = H.HeadState(iter=int(g[f"{tag}_pre_iter"]), t=float(g[f"{tag}_pre_t"]))
     out = H.head_forward_backward(kind, g[f"{tag}_x"], g[f"{tag}_w"], g[f"{tag}_y"],
-                                  H.HeadHyper.default(kind), st, dtype=np.float32)
+                                  hyper_for(name), st, dtype=np.float32)
     # logits are cosines x 64: the north-star bar is 1e-3; the fp32 restatement sits far below it,
     # EXCEPT where the reference itself is ill-conditioned: a target cosine within ~1e-5 of +-1
     # makes sqrt(1-c^2) (ArcFace :281, Curricular :555) swing by 3e-4 per ulp of c.  Those rows
@@ -63,7 +74,7 @@ def test_head_float64_gradients_tight(golden_dir, name):
     kind = KINDS[name]
     st = H.HeadState(iter=int(g["warm_pre_iter"]), t=float(g["warm_pre_t"]))
     out = H.head_forward_backward(kind, g["warm_x"], g["warm_w"], g["warm_y"],
-                                  H.HeadHyper.default(kind), st, dtype=np.float64)
+                                  hyper_for(name), st, dtype=np.float64)
     y = g["warm_y"]
     ty = g["warm_cos_s"][np.arange(len(y)), y] / (64.0 if kind != H.SPHERE else g["warm_norms"][:, 0])
     ok = ~((np.abs(ty) > 1 - 1e-5) & (kind in (H.ARC, H.CURR)))   # see test_head_matches_reference
