@@ -179,8 +179,13 @@ def test_model_classes_keep_reference_contract():
         get_backbone("vgg16")
     with pytest.raises(NotImplementedError):
         get_backbone("resnet18")
-    with pytest.raises(NotImplementedError):
-        ArcFace(512, 10, easy_margin=True)
+    assert ArcFace(512, 10, easy_margin=True).frx_flags == 1 and ArcFace(512, 10, easy_margin=False).frx_flags == 0
+    with pytest.raises(NotImplementedError):           # the dormant model-parallel branch (criterion.py:268-278)
+        ArcFace(512, 10, device_id=[0, 1], easy_margin=False)
+    from utils.criterion import SphereFace
+    assert SphereFace(512, 10, m=4).m == 4
+    with pytest.raises(ValueError):
+        SphereFace(512, 10, m=6)
     with pytest.raises(FrxError):                      # fails loudly off-GPU: no CPU fallback
         m(torch.zeros(2, 3, 112, 112), torch.zeros(2, dtype=torch.long))
     sd = {k: v.clone() for k, v in m.state_dict().items()}
