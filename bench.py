@@ -148,6 +148,8 @@ def parse_args():
     ap.add_argument("--split", action="store_true",
                     help="run the data-parallel step structure (graph segments + RCCL all-reduces between them) on one GPU")
     ap.add_argument("--bf16-buckets", action="store_true", help="data parallel: gradients travel as bf16")
+    ap.add_argument("--shard-head", action="store_true",
+                    help="class-sharded head (SURVEY 8f-4): each rank owns classes/N columns, no head gradient on the wire")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     return ap.parse_args()
 
@@ -170,7 +172,12 @@ def run(args):
 
     from frx import ddp, engine as E, ops
     dt = ops.BF16 if args.dtype == "bf16" else ops.F32
-    eng = E.FaceEngine(args.head, args.classes, args.batch, dtype=dt, device=dev, seed=0, lambda_g=args.lambda_g)
+    if args.shard_head and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29512")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    eng = E.FaceEngine(args.head, args.classes, args.batch, dtype=dt, device=dev, seed=0, lambda_g=args.lambda_g,
+                       shard=(rank, world) if args.shard_head else None)
     g = torch.Generator().manual_seed(1234 + rank)
     nb = 4
     batches = [((torch.rand(args.batch, 3, 112, 112, generator=g) * 2 - 1).to(dev),
@@ -225,7 +232,7 @@ def run(args):
     if rank == 0:
         ips = world * args.batch * args.steps / dt_s
         flop_img = FLOP_PER_IMG_BACKBONE + 6.0 * 512 * args.classes
-        agg = kernel_pass(eng, images, labels) if world == 1 else {}      # (eng.allreduce is unset: plain single-GPU step)
+        agg = kernel_pass(eng, images, labels) if (world == 1 and not args.shard_head) else {}      # (plain single-GPU eager step)
         roof = None
         if agg:
             label, (secs, flops, launches, nbytes) = max(agg.items(), key=lambda kv: kv[1][0])
@@ -271,11 +278,12 @@ def run(args):
                                    f"random-init weights, BASELINE configs[1]",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
                        "hip_graph": bool(graph), "graph_segments": len(stepper.segments()) if graph else 0,
-                       "bf16_grad_buckets": bool(stepper.bf16), "lr": args.lr, "final_loss": round(loss, 4)},
+                       "bf16_grad_buckets": bool(stepper.bf16), "class_sharded_head": bool(args.shard_head),
+                       "lr": args.lr, "final_loss": round(loss, 4)},
             "step_mfma_frac": round(ips * flop_img / (world * PEAK_BF16_TFLOPS * 1e12), 4),
             "roofline": roof, "cpu_baseline": cpu,
         }
-    if world > 1 or args.split:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     return result if rank == 0 else None

@@ -152,7 +152,8 @@ class DataParallelStep:
         torch.cuda.synchronize(self.eng.device)
         for items in self._segment_items():
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # (thread-local capture mode: RCCL's watchdog thread polls events while this thread captures)
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 for _, fn, _ in items:
                     fn()
             graphs.append(g)

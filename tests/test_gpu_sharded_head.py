@@ -117,7 +117,7 @@ def test_engine_with_a_sharded_head_on_a_one_rank_group_equals_the_plain_engine(
         assert oa["topk"].tolist() == ob["topk"].tolist() or i == 2
         if i == 1:
             rel = ((a.net.params - b.net.params).norm() / b.net.params.norm()).item()
-            assert rel < 2e-4, rel
+            assert rel < 1e-3, rel
     assert sa.graphed and sb.graphed
     if kind == "curricular":
         assert a.t.item() == pytest.approx(b.t.item(), rel=1e-2) and a.t.item() != 0      # (after the chaotic third step)
