@@ -27,6 +27,16 @@ static int launch_igemm(hipStream_t st, ConvArgs a, int dtype) {
   if (a.mode == MODE_DGRAD && a.epi_bnbwd && a.addend && c.bm == 128 && c.bn == 128 && !getenv("FRX_IGEMM_TILE")) c = TileCfg{128, 64, 4, 64};
   FRX_CHECK_ARG(c.kc == 64 || (a.Kc * (int)esz) % c.kc == 0, "igemm: %d channels do not fill %d-byte K-chunks", a.Kc, c.kc);
   a.tilesM = cdiv(a.M, c.bm);
+  if (a.s2c) {                     // tiles per parity class (h & 1, w & 1), class-major
+    int t = 0;
+    for (int cls = 0; cls < 4; ++cls) {
+      a.cls_tile0[cls] = t;
+      const long mc = (long)a.N * ((a.Ho - (cls >> 1) + 1) / 2) * ((a.Wo - (cls & 1) + 1) / 2);
+      t += cdiv(mc, c.bm);
+    }
+    a.cls_tile0[4] = t;
+    a.tilesM = t;
+  }
   a.tilesN = cdiv(a.Ncol, c.bn);
   const int grid = (int)round_up(a.tilesM, 8) * a.tilesN;
   int epi = EPI_PLAIN;
@@ -122,6 +132,7 @@ static int dgrad_impl(int device, frx_stream_t stream, const frx_conv_desc* d, c
   a.stride = d->stride; a.pad = d->pad;
   a.M = d->N * d->Hi * d->Wi;
   a.mode = MODE_DGRAD;
+  a.s2c = (d->stride == 2 && (d->R > 1 || d->S > 1) && !getenv("FRX_DGRAD_NO_S2C")) ? 1 : 0;
   if (f) {
     if (f->pro_y) {
       FRX_CHECK_ARG(f->pro_coef != nullptr, "conv_dgrad_bn: pro_y needs pro_coef");
@@ -165,7 +176,13 @@ extern "C" int frx_conv_dgrad_bn(int device, frx_stream_t stream, const frx_conv
 extern "C" int frx_conv_dgrad_stat_rows(const frx_conv_desc* d) {
   if (check_conv(d) != FRX_OK) return -1;
   const long M = (long)d->N * d->Hi * d->Wi;
-  return cdiv(M, pick_tile(M, d->Ci, false, false).bm);
+  const int bm = pick_tile(M, d->Ci, false, false).bm;
+  if (d->stride == 2 && (d->R > 1 || d->S > 1)) {       // parity-class tiles (launch_igemm)
+    int t = 0;
+    for (int cls = 0; cls < 4; ++cls) t += cdiv((long)d->N * ((d->Hi - (cls >> 1) + 1) / 2) * ((d->Wi - (cls & 1) + 1) / 2), bm);
+    return t;
+  }
+  return cdiv(M, bm);
 }
 
 // Geometry shared by the per-layer and the grouped launches; the pixel split is the caller's policy.

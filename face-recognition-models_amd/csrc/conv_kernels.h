@@ -76,6 +76,13 @@ struct ConvArgs {
   int mode;
   int tilesM, tilesN;
   unsigned xbytes, wbytes;   // sizes of X (and X2) and W in bytes: buffer-load bounds (out-of-range reads return 0)
+  // Stride-2 input gradient by output-pixel PARITY CLASS (dgrad of a strided RxS conv): output pixel (h, w) only
+  // receives taps with r = h + pad, s = w + pad (mod 2), so the four classes (h & 1, w & 1) are dense convolutions over a
+  // quarter of the pixels each with 1 + 2 + 2 + 4 of the 9 taps -- 2.25 taps per pixel instead of 9 of which 3/4 gather
+  // zeros.  One launch: tiles [cls_tile0[c], cls_tile0[c + 1]) belong to class c = 2 * (h & 1) + (w & 1); rows inside a
+  // class run over (n, h', w') with h = 2 h' + (c >> 1), w = 2 w' + (c & 1).
+  int s2c;
+  int cls_tile0[5];
 };
 
 __device__ __forceinline__ void load8(const float* __restrict__ p, float (&o)[8]) {
@@ -247,7 +254,17 @@ __global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN 
   const int xcd = bid & 7, local = bid >> 3;
   const int mt = (local / a.tilesN) * 8 + xcd, nt = local % a.tilesN;
   if (mt >= a.tilesM) return;
-  const int m0 = mt * BM, n0 = nt * BN;
+  // parity-class mode (a.s2c): this tile's class, the class's pixel grid and row count (all block-uniform)
+  int cls = 0, pa = 0, pb = 0, Hc = a.Ho, Wc = a.Wo, Mc = a.M, mtl = mt;
+  if (MODE == MODE_DGRAD && a.s2c) {
+    cls = (mt >= a.cls_tile0[1]) + (mt >= a.cls_tile0[2]) + (mt >= a.cls_tile0[3]);
+    pa = cls >> 1; pb = cls & 1;
+    Hc = (a.Ho - pa + 1) >> 1; Wc = (a.Wo - pb + 1) >> 1;
+    Mc = a.N * Hc * Wc;
+    mtl = mt - a.cls_tile0[cls];
+  }
+  const bool s2c = MODE == MODE_DGRAD && a.s2c;
+  const int m0 = mtl * BM, n0 = nt * BN;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -255,7 +272,10 @@ __global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN 
   const T* __restrict__ X = reinterpret_cast<const T*>(a.X);
   const T* __restrict__ Wp = reinterpret_cast<const T*>(a.W);
   const int Ktot = a.R * a.S * a.Kc;
-  const int nk = (MODE == MODE_STEM) ? (a.R * 32) / CE : Ktot / CE;
+  const int tr0 = s2c ? ((pa + a.pad) & 1) : 0, ts0 = s2c ? ((pb + a.pad) & 1) : 0;      // first tap of the class, step 2
+  const int tstep = s2c ? 2 : 1;
+  const int ntaps = s2c ? ((a.R - tr0 + 1) >> 1) * ((a.S - ts0 + 1) >> 1) : a.R * a.S;
+  const int nk = (MODE == MODE_STEM) ? (a.R * 32) / CE : (ntaps * a.Kc) / CE;
   const int ldw = (MODE == MODE_STEM) ? a.R * 32 : Ktot;   // weight row length in elements
 
   // ---- per-thread gather bookkeeping (rows fixed across the K loop)
@@ -265,16 +285,17 @@ __global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN 
 #pragma unroll
   for (int i = 0; i < ALD; ++i) {
     const int m = m0 + srow + RPP * i;
-    rok[i] = m < a.M;
+    rok[i] = m < Mc;
     const int mm = rok[i] ? m : 0;
     int n, oh, ow;
     if (pw) {                                                    // pointwise: the gathered pixel IS pixel m
       n = 0; oh = 0; ow = mm;
     } else {
-      const int hw = a.Ho * a.Wo;
+      const int hw = Hc * Wc;
       n = mm / hw;
       const int rem = mm - n * hw;
-      oh = rem / a.Wo; ow = rem - oh * a.Wo;
+      oh = rem / Wc; ow = rem - oh * Wc;
+      if (s2c) { oh = 2 * oh + pa; ow = 2 * ow + pb; }
     }
     rn[i] = n;
     if (pw) { rh[i] = 0; rw[i] = mm; }
@@ -309,7 +330,7 @@ __global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN 
     __syncthreads();
   }
 
-  int tr = 0, ts = 0, c0 = 0;   // current tap (r, s) and channel offset of the K-chunk
+  int tr = tr0, ts = ts0, c0 = 0;   // current tap (r, s) and channel offset of the K-chunk
   // Register ring of PD K-chunks: HBM/L2 latency (~2k cycles under load) is several chunks of MFMA work,
   // so loads run PD-1 chunks ahead of the LDS write that consumes them.
   uint4 ra[PD][ALD], rb[PD][BLD];
@@ -361,7 +382,7 @@ __global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN 
       m |= (aok[i] ? 1u : 0u) << i;
     }
     rmask[slot] = m;
-    const int sob = kc * KC;
+    const int sob = s2c ? ((tr * a.S + ts) * a.Kc + c0) * (int)sizeof(T) : kc * KC;   // (the class walks a subset of the taps)
 #pragma unroll
     for (int i = 0; i < BLD; ++i) rb[slot][i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rsrcW, bvoff[i], sob, 0));
     // advance the tap walker to chunk kc+1
@@ -369,7 +390,7 @@ __global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN 
     const int span = (MODE == MODE_STEM) ? 32 : a.Kc;
     if (c0 >= span) {
       c0 = 0;
-      if (MODE == MODE_STEM) { ++tr; } else if (++ts == a.S) { ts = 0; ++tr; }
+      if (MODE == MODE_STEM) { ++tr; } else { ts += tstep; if (ts >= a.S) { ts = ts0; tr += tstep; } }
       if (kc + 1 < nk) set_tap();
     }
   };
@@ -496,6 +517,23 @@ __global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN 
   const int ncol0 = n0 + wn * WTN + 8 * fq;                     // first of its 8 channels for pair a2 = 0
   const unsigned elem0 = (unsigned)mrow * (unsigned)a.Ncol + (unsigned)ncol0;   // element index of (mrow, ncol0)
   const unsigned rstep = 16u * (unsigned)a.Ncol;                // elements between fragment rows (scalar)
+  // parity-class mode: fragment rows are class-local pixels; erow[i] = element index of (their real row, ncol0), or an
+  // index whose byte offset lies past every tensor (loads give 0, stores are dropped) for rows past the class
+  unsigned erow[FM];
+  int mreal[FM];
+#pragma unroll
+  for (int i = 0; i < FM; ++i) {
+    const int m = mrow + 16 * i;
+    if (s2c) {
+      const int hw = Hc * Wc, n = m / hw, rem = m - n * hw, hq = rem / Wc, wq = rem - hq * Wc;
+      mreal[i] = (n * a.Ho + 2 * hq + pa) * a.Wo + 2 * wq + pb;
+      erow[i] = m < Mc ? (unsigned)mreal[i] * (unsigned)a.Ncol + (unsigned)ncol0 : (0x80000000u / (unsigned)OSZ);   // (x OSZ = 2 GiB: out of every descriptor)
+      if (m >= Mc) mreal[i] = a.M;
+    } else {
+      mreal[i] = m;
+      erow[i] = elem0 + (unsigned)i * rstep;
+    }
+  }
   unsigned addvo[ADD ? FM : 1];                                 // byte offset of (row i, ncol0) inside the addend
   unsigned addbytes = ybytes;
   if constexpr (ADD) {
@@ -504,14 +542,14 @@ __global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN 
       addbytes = (unsigned)a.N * Hc * Wc * a.Ncol * OSZ;
 #pragma unroll
       for (int i = 0; i < FM; ++i) {
-        const int m = mrow + 16 * i;
+        const int m = mreal[i];
         const int n = m / hw, rem = m - n * hw, h = rem / a.Wo, w = rem - h * a.Wo;
         const bool on = m < a.M && !((h | w) & 1);
         addvo[i] = on ? (unsigned)((((n * Hc + (h >> 1)) * Wc + (w >> 1)) * a.Ncol + ncol0) * OSZ) : 0x80000000u;
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < FM; ++i) addvo[i] = (elem0 + (unsigned)i * rstep) * OSZ;
+      for (int i = 0; i < FM; ++i) addvo[i] = erow[i] * OSZ;
     }
   }
   const __amdgpu_buffer_rsrc_t rsrcAdd = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(ADD ? a.addend : a.Y), 0, addbytes, 0x00020000);
@@ -534,12 +572,14 @@ __global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN 
     float av[ADD ? FM : 1][8], yv[(EPI == EPI_BNBWD || EPI == EPI_BNBWD_OUT) ? FM : 1][8], ov[EPI == EPI_BNBWD_OUT ? FM : 1][8];
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-      const int so_t = (int)(i * rstep * sizeof(T)), so_o = (int)(i * rstep * OSZ);
+      // (row i of the tile: a scalar offset from the lane's first row -- or, in parity-class mode, its own vector offset)
+      const int so_t = s2c ? 0 : (int)(i * rstep * sizeof(T));
+      const unsigned eoff_i = s2c ? erow[i] + 32u * a2 : eoff;
       if constexpr (ADD) buf_load8<OUT32 ? 4 : 2>(rsrcAdd, addvo[i] + 32u * a2 * OSZ, 0, av[i]);
-      if constexpr (EPI == EPI_BNBWD || EPI == EPI_BNBWD_OUT) buf_load8<sizeof(T)>(rsrcEy, eoff * (unsigned)sizeof(T), so_t, yv[i]);
+      if constexpr (EPI == EPI_BNBWD || EPI == EPI_BNBWD_OUT) buf_load8<sizeof(T)>(rsrcEy, eoff_i * (unsigned)sizeof(T), so_t, yv[i]);
       if constexpr (EPI == EPI_BNBWD_OUT) {
         if (ebits) {        // this lane's 8 channels are 8 / VEC groups: 1 mask byte (bf16) or 2 (fp32); expand to +-1
-          const unsigned gidx = (eoff + (unsigned)i * rstep) / (unsigned)VEC;
+          const unsigned gidx = (s2c ? eoff_i : eoff + (unsigned)i * rstep) / (unsigned)VEC;
           unsigned m8;
           if constexpr (VEC == 8) m8 = __builtin_amdgcn_raw_buffer_load_b8(rsrcEo, gidx, 0, 0);
           else m8 = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rsrcEo, gidx, 0, 0) |
@@ -547,13 +587,13 @@ __global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN 
 #pragma unroll
           for (int e = 0; e < 8; ++e) ov[i][e] = ((m8 >> e) & 1u) ? 1.f : 0.f;
         } else {
-          buf_load8<sizeof(T)>(rsrcEo, eoff * (unsigned)sizeof(T), so_t, ov[i]);
+          buf_load8<sizeof(T)>(rsrcEo, eoff_i * (unsigned)sizeof(T), so_t, ov[i]);
         }
       }
     }
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
-      const int so_o = (int)(i * rstep * OSZ);
+      const unsigned sto = s2c ? (erow[i] + 32u * a2) * OSZ : eoff * OSZ + (unsigned)(i * rstep * OSZ);   // byte offset of this row's store
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * a2 + (e >> 2)][e & 3];
@@ -580,13 +620,13 @@ __global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN 
         // NOTE soffset must stay the literal 0 on stores: with an SGPR soffset hipcc (ROCm 7.2) assumes the
         // ">64-bit store data overwritten by the next VALU" hazard away and re-uses the data registers in
         // the very next instruction; on gfx950 that corrupts sporadic dwords once several blocks share a CU.
-        __builtin_amdgcn_raw_buffer_store_b128(s0, rsrcY, eoff * 4u + (unsigned)so_o, 0, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(s1, rsrcY, eoff * 4u + (unsigned)so_o + 16u, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(s0, rsrcY, sto, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(s1, rsrcY, sto + 16u, 0, 0);
       } else {
         bf16x8 t;
 #pragma unroll
         for (int e = 0; e < 8; ++e) { t[e] = (bf16_t)v[e]; v[e] = (float)t[e]; }   // stats of what the next layer reads
-        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<u32x4_t*>(&t), rsrcY, eoff * 2u + (unsigned)so_o, 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<u32x4_t*>(&t), rsrcY, sto, 0, 0);
       }
       if constexpr (EPI == EPI_STATS) {
 #pragma unroll

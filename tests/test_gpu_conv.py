@@ -154,7 +154,7 @@ def test_fc_as_conv(dtype):
 
 @pytest.mark.parametrize("dtype", [0, 1], ids=["f32", "bf16"])
 @pytest.mark.parametrize("shape", [(64, 256, 1, 1, 28), (256, 64, 1, 1, 28), (512, 128, 1, 1, 14), (256, 512, 1, 2, 28),
-                                   (128, 128, 3, 1, 14), (2048, 512, 1, 1, 4)],
+                                   (128, 128, 3, 1, 14), (2048, 512, 1, 1, 4), (256, 256, 3, 2, 14), (512, 512, 3, 2, 7)],
                          ids=lambda s: f"{s[0]}x{s[1]}k{s[2]}s{s[3]}h{s[4]}")
 @pytest.mark.parametrize("merge_mask", [False, True], ids=["relu_bn_mask", "merge_mask"])
 def test_fused_bn_backward_in_dgrad_wgrad(dtype, shape, merge_mask):
