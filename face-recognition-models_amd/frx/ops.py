@@ -367,6 +367,8 @@ def conv_dgrad_bn(d, dz, w_crsk, dx, addend=None, pro_y=None, pro_coef=None, epi
                          (pro_y, pro_coef, epi_y, epi_out, epi_scale, epi_shift, epi_mean, epi_invstd, epi_partial, epi_out_bits)],
                        int(addend_stride), 0 if pro_dy_out is None else pro_dy_out.data_ptr())
     bm, bn = _igemm_tile(d.N * d.Hi * d.Wi, d.Ci, fwd=False)
+    if (bm, bn) == (128, 128) and addend is not None and epi_y is not None:
+        bn = 64                      # conv1-type input gradients take the 128x64 tile (launch_igemm in csrc/conv.hip)
     _timed(f"k_igemm<{_dt_name(d.dtype)},{bm},{bn}>", conv_flops(d), dz, lambda: check(
         _lib.lib().frx_conv_dgrad_bn(_dev(dz), _stream(dz), C.byref(d), _p(dz), _p(w_crsk), _p(addend), _p(dx),
                                      C.byref(f)), "frx_conv_dgrad_bn"),
