@@ -1063,6 +1063,20 @@ extern "C" int frx_head_fwd_loss(int device, frx_stream_t stream, const frx_head
   return FRX_OK;
 }
 
+// After frx_head_fwd_cos: the clamped target cosine of every row (what the elastic heads' plus=True variant ranks its
+// margins by, criterion.py:1006-1011 / 1117-1122).
+extern "C" int frx_head_target_cos(int device, frx_stream_t stream, const frx_head_desc* d, void* ws, size_t ws_bytes,
+                                   float* ty_out) {
+  if (int rc = check_desc(d)) return rc;
+  FRX_CHECK_ARG(ws && ty_out, "head_target_cos: NULL pointer");
+  FRX_ENTER(device);
+  HeadWs W = carve(d, ws);
+  if (ws_bytes < W.bytes) { set_error("head workspace too small: %zu < %zu", ws_bytes, W.bytes); return FRX_ERR_WORKSPACE; }
+  hipLaunchKernelGGL(k_copy_f32, dim3(cdiv(d->N, 256)), dim3(256), 0, (hipStream_t)stream, (const float*)W.ty, ty_out, (long)d->N);
+  FRX_LAUNCH_CHECK();
+  return FRX_OK;
+}
+
 // ---------------------------------------------------------------------------------------- class-sharded head
 extern "C" int frx_head_shard_cos(int device, frx_stream_t stream, const frx_head_desc* d, const float* x, const float* w,
                                   const int64_t* labels, void* ws, size_t ws_bytes, float* ty_out) {

@@ -56,6 +56,7 @@ _SIGS = {
                                _P, _P, _P, _P, _P, _P]),
     "frx_head_bwd": (C.c_int, [C.c_int, _P, C.POINTER(HeadDesc), _P, _P, _P, _P, _P, _P, C.c_size_t,
                                _P, _P, C.c_int]),
+    "frx_head_target_cos": (C.c_int, [C.c_int, _P, C.POINTER(HeadDesc), _P, C.c_size_t, _P]),
     "frx_head_shard_cos": (C.c_int, [C.c_int, _P, C.POINTER(HeadDesc), _P, _P, _P, _P, C.c_size_t, _P]),
     "frx_head_shard_rows": (C.c_int, [C.c_int, _P, C.POINTER(HeadDesc), _P, _P, _P, _P, C.c_size_t, _P]),
     "frx_head_shard_rescale": (C.c_int, [C.c_int, _P, C.c_int, _P, _P, _P]),

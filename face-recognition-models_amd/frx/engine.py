@@ -643,7 +643,7 @@ class FaceEngine:
     """Backbone + margin head + fused SGD: one training step = forward, CE, backward, update."""
 
     def __init__(self, kind, num_classes, batch, dtype=BF16, device="cuda:0", s=None, m=None, momentum=0.01, seed=None,
-                 share=None, head_p=None, head_flags=None, lambda_g=0.0, elastic_std=0.0125, shard=None):
+                 share=None, head_p=None, head_flags=None, lambda_g=0.0, elastic_std=0.0125, shard=None, elastic_plus=False):
         """shard = (rank, world): class-sharded head -- this replica owns the class columns
         [rank * Cs, (rank + 1) * Cs), Cs = ceil(C / world); the batch of all ranks is gathered for the head, no head
         gradient crosses the wire (frx/ddp.py: sharded_plan).  The backbone stays a plain data-parallel replica."""
@@ -670,6 +670,7 @@ class FaceEngine:
         self.device = self.net.device
         self.head_p = tuple(HEAD_P_DEFAULTS.get(self.kind, ()) if head_p is None else head_p)
         self.elastic_std = float(elastic_std)
+        self.elastic_plus = bool(elastic_plus) and self.kind in ELASTIC_KINDS      # rank-matched margins (criterion.py:1006-1011)
         head_flags = HEAD_FLAG_DEFAULTS.get(self.kind, 0) if head_flags is None else head_flags
         self.head = ops.HeadContext(self.kind, self.N_g, FEATURE_DIM, self.C, self.s, self.m, momentum, device=self.device,
                                     p=self.head_p, flags=head_flags, lambda_g=lambda_g,
@@ -691,6 +692,7 @@ class FaceEngine:
             self.t = torch.zeros(num_classes * FEATURE_DIM + num_classes, device=self.device) if share is None else share.t
         elif self.kind in ELASTIC_KINDS:
             self.t = torch.full((batch,), float(self.m), device=self.device)
+            self.margin_scratch = torch.empty(batch, device=self.device)
         elif self.kind == ops.ADA:
             self.t = torch.tensor([20.0, 100.0], device=self.device) if share is None else share.t
         else:
@@ -759,7 +761,7 @@ class FaceEngine:
         feats = self.net.forward(images)
         lamb = self._lamb() if self.kind == ops.SPHERE else 0.0
         self.last = ops.head_forward(self.head, feats, self.head_w(), labels, state_t=self.t, lamb=lamb,
-                                     want_logits=want_logits, ty_allreduce=self.ty_allreduce)
+                                     want_logits=want_logits, ty_allreduce=self.ty_allreduce, elastic_plus=self.elastic_plus)
         self.last["feats"] = feats
         return self.last
 
@@ -833,6 +835,8 @@ class FaceEngine:
         ops.head_forward_cos(self.head, feats, self.head_w(), labels, state_t=self.t, ty_sum=self.ty_sum)
 
     def stage_upper(self, labels):
+        if self.elastic_plus:
+            ops.rank_matched_margins(self.head, self.t, self.margin_scratch)
         out = ops.head_forward_loss(self.head, labels, self.ty_sum, self.N * self.world, state_t=self.t,
                                     lamb=None if self.kind == ops.SPHERE else 0.0)
         out["feats"] = self.net.feats

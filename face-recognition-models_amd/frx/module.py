@@ -110,7 +110,7 @@ class NativeFaceNet(nn.Module):
         eng = E.FaceEngine(self.kind, h.num_classes, n, dtype=self._dtype, device=device, s=h.s, m=float(h.m),
                            momentum=getattr(h, "momentum", 0.01), share=self._primary,
                            head_p=getattr(h, "frx_p", None), head_flags=getattr(h, "frx_flags", 0),
-                           elastic_std=getattr(h, "std", 0.0125))
+                           elastic_std=getattr(h, "std", 0.0125), elastic_plus=bool(getattr(h, "plus", False)))
         if self._primary is None:
             self._adopt(eng)
             if self._dp is not None:
@@ -298,7 +298,7 @@ class _TrainForward(torch.autograd.Function):
             eng.sample_margins()                       # elastic heads: this step's margins (criterion.py:1002,1113)
             feats = eng.net.forward(x.contiguous())
             out = ops.head_forward(eng.head, feats, eng.head_w(), labels, state_t=eng.t, lamb=lamb, want_logits=True,
-                                   ty_allreduce=eng.ty_allreduce)
+                                   ty_allreduce=eng.ty_allreduce, elastic_plus=eng.elastic_plus)
         anchor = model._head_param()
         is_mag = eng.kind == ops.MAG
         logits, loss_g = _TrainForward.apply(anchor, out["logits"], out["loss_g"][0] if is_mag else None, model, eng, labels)

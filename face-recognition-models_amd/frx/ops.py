@@ -119,6 +119,34 @@ def head_forward_cos(ctx: HeadContext, x, w, labels, state_t=None, ty_sum=None):
     return ty_sum
 
 
+def head_target_cos(ctx: HeadContext, out):
+    """out [N] <- clamped target cosines of the rows (valid after head_forward_cos)"""
+    _chk(out, torch.float32, "out")
+    check(_lib.lib().frx_head_target_cos(_dev(out), _stream(out), C.byref(ctx.desc), _p(ctx.ws), ctx.nbytes, _p(out)),
+          "frx_head_target_cos")
+    return out
+
+
+def rank_matched_margins(ctx: HeadContext, margins, scratch):
+    """Elastic heads, plus=True (criterion.py:1006-1011 / 1117-1122), in place on `margins` [N]:
+    rank = argsort(target cosine, descending); margins <- sort(margins)[rank]   (the reference's own indexing)."""
+    head_target_cos(ctx, scratch)
+    rank = torch.sort(scratch, descending=True).indices
+    margins.copy_(torch.sort(margins).values[rank])
+
+
+def head_forward(ctx: HeadContext, x, w, labels, state_t=None, lamb=0.0, want_logits=False,
+                 ty_allreduce=None, elastic_plus=False):
+    """Both phases.  ty_allreduce: optional callable(tensor[1]) -> count, summing the target-cosine sum over
+    data-parallel ranks between them (CurricularFace EMA).  elastic_plus: rank-match the margins in
+    state_t to the target cosines between the phases."""
+    tys = head_forward_cos(ctx, x, w, labels, state_t)
+    if elastic_plus:
+        rank_matched_margins(ctx, state_t, torch.empty_like(state_t))
+    count = ctx.desc.N if ty_allreduce is None else ty_allreduce(tys)
+    return head_forward_loss(ctx, labels, tys, count, state_t, lamb, want_logits)
+
+
 def head_forward_loss(ctx: HeadContext, labels, ty_sum, count, state_t=None, lamb=0.0, want_logits=False):
     """Phase 2: state update from the (global) target-cosine sum over `count` samples, margin + CE + top-k row sweep.
     Returns dict(loss[1], topk[2] int32, norms[N], lse[N], cos_s, logits[, loss_g, row_param]).
@@ -148,15 +176,6 @@ def head_forward_loss(ctx: HeadContext, labels, ty_sum, count, state_t=None, lam
         check(L.frx_head_aux(dev, st, C.byref(ctx.desc), _p(state_t), _p(ctx.ws), ctx.nbytes, _p(o["loss_g"]),
                              _p(o["row_param"])), "frx_head_aux")
     return o
-
-
-def head_forward(ctx: HeadContext, x, w, labels, state_t=None, lamb=0.0, want_logits=False,
-                 ty_allreduce=None):
-    """Both phases.  ty_allreduce: optional callable(tensor[1]) -> count, summing the target-cosine sum over
-    data-parallel ranks between them (CurricularFace EMA)."""
-    tys = head_forward_cos(ctx, x, w, labels, state_t)
-    count = ctx.desc.N if ty_allreduce is None else ty_allreduce(tys)
-    return head_forward_loss(ctx, labels, tys, count, state_t, lamb, want_logits)
 
 
 # ---- class-sharded head: the four compute phases between the caller's collectives (include/frx.h)

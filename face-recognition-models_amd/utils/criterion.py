@@ -156,15 +156,14 @@ class AdaFace(_HeadBase):
 
 class _Elastic(_HeadBase):
     """criterion.py:951-1021 / 1054-1145; parameter `kernel` [D, C].  The per-row margin is drawn on the device each
-    step (normal(m, std) clamped to [m - std, m + std]); `plus` (rank-matched margins, :1006-1011) has no native path."""
+    step (normal(m, std) clamped to [m - std, m + std]); with `plus` the sorted margins are then assigned by the rank of
+    the rows' target cosines (:1006-1011, :1117-1122) between the two head phases (ops.rank_matched_margins)."""
 
     def __init__(self, feat_dim, num_class, s=64.0, m=0.35, std=0.0125, plus=False, device_id=None):
         super().__init__()
         _no_model_parallel(device_id)
-        if plus:
-            raise NotImplementedError("the elastic heads' plus=True variant is not implemented (config.py ships plus=False)")
         self.feat_dim, self.num_class, self.num_classes = feat_dim, num_class, num_class
-        self.s, self.m, self.std, self.plus, self.device_id = s, m, std, False, None
+        self.s, self.m, self.std, self.plus, self.device_id = s, m, std, bool(plus), None
         self.kernel = nn.Parameter(torch.empty(feat_dim, num_class))
         nn.init.normal_(self.kernel, std=0.01)
 
@@ -266,7 +265,8 @@ class _StandaloneHead(torch.autograd.Function):
             t = torch.empty(N, device=feats.device).normal_(head.m, head.std).clamp_(head.m - head.std, head.m + head.std)
         elif kind == ops.VPL:
             t = torch.cat([head.mem.reshape(-1), head.life.reshape(-1)]).float().to(feats.device)
-        out = ops.head_forward(ctx, x, w.detach().contiguous(), labels.contiguous(), state_t=t, lamb=lamb, want_logits=True)
+        out = ops.head_forward(ctx, x, w.detach().contiguous(), labels.contiguous(), state_t=t, lamb=lamb, want_logits=True,
+                               elastic_plus=bool(getattr(head, "plus", False)) and kind in (ops.ELASTIC_ARC, ops.ELASTIC_COS))
         if kind == ops.ADA:
             head.batch_mean, head.batch_std = t[0:1].clone(), t[1:2].clone()
         elif kind == ops.VPL:

@@ -112,6 +112,9 @@ int frx_head_fwd_loss(int device, frx_stream_t stream, const frx_head_desc* d, c
                       float* state_t, const float* ty_sum, int64_t ty_count, void* ws, size_t ws_bytes,
                       float* cos_s, float* logits, float* norms, float* loss, float* lse,
                       int32_t* topk);
+/* After frx_head_fwd_cos: ty_out [N] <- the clamped target cosine of every row.  The elastic heads' plus=True variant
+ * (criterion.py:1006-1011, 1117-1122) assigns its sampled margins by the rank of these before frx_head_fwd_loss. */
+int frx_head_target_cos(int device, frx_stream_t stream, const frx_head_desc* d, void* ws, size_t ws_bytes, float* ty_out);
 /* VPL only, between frx_head_fwd_cos and frx_head_fwd_loss (frx_head_fwd calls it itself): per-class mean of the batch's
  * raw features into `mem`, `life` = delta for those classes, life -= 1 for all classes, cosine against the normalised
  * memory and the lamda blend of criterion.py:699-722 written over the cosines in the workspace (flags bit 1 clear: no-op). */

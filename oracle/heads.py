@@ -10,8 +10,8 @@ Follows the reference (paths relative to /root/reference/main_code):
   CurricularFace utils/criterion.py:527-587   (ctor :496-519)
   MV_Softmax     utils/criterion.py:388-450   (ctor :334-377; margin types 'am' and 'arc')
   AdaFace        utils/criterion.py:848-907   (ctor :802-841)
-  ElasticArcFace utils/criterion.py:1089-1145 (ctor :1061-1083; plus=False)
-  ElasticCosFace utils/criterion.py:982-1021  (ctor :955-976; plus=False)
+  ElasticArcFace utils/criterion.py:1089-1145 (ctor :1061-1083; plus=False and plus=True)
+  ElasticCosFace utils/criterion.py:982-1021  (ctor :955-976; plus=False and plus=True)
   MagFace        utils/criterion.py:1241-1291 (ctor :1185-1222)
   VPLArcFace     utils/criterion.py:686-752   (ctor :626-674)
   CE             utils/model_utils.py:556,179 (nn.CrossEntropyLoss, mean)
@@ -67,6 +67,7 @@ class HeadHyper:
     lamda: float = 0.15      # VPLArcFace (config.py:43-44)
     delta: float = 100.0
     memory_on: bool = True   # VPLArcFace.norm_training_flag (criterion.py:671)
+    plus: bool = False       # Elastic heads: rank-matched margins (criterion.py:1006-1011, 1117-1122)
 
     @staticmethod
     def default(kind: int) -> "HeadHyper":
@@ -265,6 +266,9 @@ def head_forward_backward(kind, x, w, labels, hyper: HeadHyper, state: HeadState
         lo, hi = dt(-1) + dt(1e-7), dt(1) - dt(1e-7)
         c = np.clip(c_raw, lo, hi)                                 # :997 / :1108
         mrow = np.asarray(row_margin, dtype=dtype).reshape(N, 1)
+        if hyper.plus:                                             # :1006-1011 / :1117-1122, indexing as written there:
+            rank = np.argsort(-c[rows, labels], kind="stable")     #   _, rank = sort(target_cos, descending)
+            mrow = np.sort(mrow[:, 0])[rank].reshape(N, 1)         #   margin = sort(margin)[rank]
         if kind == ELASTIC_COS:
             zc = c - onehot * mrow                                 # :1013
             dzdc = np.full_like(c, dt(hyper.s))

@@ -158,3 +158,41 @@ def test_elastic_margins_are_redrawn_on_every_graph_replay():
         assert (m - 0.5).abs().max().item() <= 0.0125 + 1e-6 and np.isfinite(out["loss"].item())
         seen.append(m)
     assert not torch.equal(seen[0], seen[1]) and not torch.equal(seen[1], seen[2])
+
+
+def _rank_matched(marg, ty):
+    """criterion.py:1006-1011 as written: margin = sort(margin)[argsort(target_cos, descending)]"""
+    return torch.sort(marg).values[torch.sort(ty, descending=True).indices]
+
+
+@pytest.mark.parametrize("cls", ["ElasticArcFaceNet", "ElasticCosFaceNet"])
+def test_elastic_plus_rank_matches_the_margins(cls):
+    """plus=True: the margins the loss phase applied are the sorted draw indexed by the rank of the target cosines, on
+    the autograd path, in the fused step, and in a replayed hipGraph of it (the sort runs inside the captured step)."""
+    from utils import model_utils as MU
+    N, C = 12, 40
+    m = _mk(cls, C, "f32", seed=6)
+    m.head.plus = True
+    x, y = _batch(N, C, 8)
+    m.train()
+    (cos_s, logits), _, _, _ = m(x, y)
+    eng = m._primary
+    assert eng.elastic_plus
+    ty = (cos_s / m.head.s)[torch.arange(N), y]
+    marg = eng.t.clone()
+    assert torch.equal(marg, _rank_matched(marg, ty)) and marg.std().item() > 0
+    zt = logits.detach()[torch.arange(N), y] / m.head.s
+    want = torch.cos(torch.acos(ty) + marg) if cls == "ElasticArcFaceNet" else ty - marg
+    assert (zt - want).abs().max().item() < LOGIT_TOL / m.head.s * 4
+    # fused step, eager then replayed
+    opt = MU.make_optimizer(m, 0.001)
+    st = m._stepper_for(eng, x)
+    for i in range(3):
+        out = st.step(x, y, 0.001)
+        torch.cuda.synchronize()
+        assert np.isfinite(out["loss"].item())
+        marg = eng.t.clone()
+        assert (marg - m.head.m).abs().max().item() <= 0.0125 + 1e-6
+        ty_step = eng.margin_scratch.clone()             # the target cosines this step ranked by
+        assert torch.equal(marg, _rank_matched(marg, ty_step))
+    assert st.graphed

@@ -48,7 +48,7 @@ def run(kind, x, w, y, hyper, state, margins=None, lambda_g=0.0, dlogits_mode=Fa
         mem = np.zeros((Cc, D), np.float32) if state.mem is None else state.mem
         life = np.zeros(Cc, np.float32) if state.life is None else state.life
         st = torch.from_numpy(np.concatenate([mem.reshape(-1), life]).astype(np.float32)).to(dev)
-    o = ops.head_forward(ctx, xd, wd, yd, state_t=st, want_logits=True)
+    o = ops.head_forward(ctx, xd, wd, yd, state_t=st, want_logits=True, elastic_plus=hyper.plus)
     if dlogits_mode:       # autograd-style: upstream gradient of the mean CE w.r.t. the returned logits
         z = o["logits"].double()
         gz = (torch.softmax(z, 1) - torch.nn.functional.one_hot(yd, Cc)) / N
@@ -110,6 +110,7 @@ def test_head_vs_oracle_seeded(name, shape):
         x[i] = wc[y[i]] / np.linalg.norm(wc[y[i]]) * (4 + 146.0 * i / N) + 0.3 * rng.randn(D)
     hy = H.HeadHyper.default(kind)
     hy.easy_margin = name == "magface_easy"
+    hy.plus = name.endswith("_plus")
     margins = None
     if kind in (H.ELASTIC_ARC, H.ELASTIC_COS):
         margins = np.clip(rng.normal(hy.m, 0.0125, N), hy.m - 0.0125, hy.m + 0.0125).astype(np.float32)

@@ -9,7 +9,8 @@ import pytest
 from oracle import heads as H
 
 CASES = {"mv_am": H.MV_AM, "mv_arc": H.MV_ARC, "adaface": H.ADA, "elastic_arc": H.ELASTIC_ARC,
-         "elastic_cos": H.ELASTIC_COS, "magface": H.MAG, "magface_easy": H.MAG, "vpl_arcface": H.VPL}
+         "elastic_cos": H.ELASTIC_COS, "magface": H.MAG, "magface_easy": H.MAG, "vpl_arcface": H.VPL,
+         "elastic_arc_plus": H.ELASTIC_ARC, "elastic_cos_plus": H.ELASTIC_COS}
 
 
 def load_case(golden_dir, name, tag):
@@ -18,6 +19,7 @@ def load_case(golden_dir, name, tag):
     hyper = H.HeadHyper.default(kind)
     if name == "magface_easy":
         hyper.easy_margin = True
+    hyper.plus = name.endswith("_plus")
     st = H.HeadState(batch_mean=float(g[f"{tag}_pre_batch_mean"]), batch_std=float(g[f"{tag}_pre_batch_std"]))
     if kind == H.VPL:
         st.mem, st.life = g[f"{tag}_pre_mem"].copy(), g[f"{tag}_pre_life"].copy()
