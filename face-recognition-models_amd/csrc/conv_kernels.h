@@ -105,6 +105,24 @@ __device__ __forceinline__ void buf_load8(__amdgpu_buffer_rsrc_t rsrc, unsigned 
   }
 }
 
+// The same 8 elements kept as loaded (4 or 8 dwords) until unpack(): holds the registers of an in-flight load, not of 8 floats
+template <int ESZ> struct Raw8 {
+  u32x4_t a, b;      // (b unused for 2-byte elements)
+  __device__ __forceinline__ void load(__amdgpu_buffer_rsrc_t rsrc, unsigned byte_off, int soff) {
+    a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off, soff, 0);
+    if constexpr (ESZ == 4) b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, byte_off + 16u, soff, 0);
+  }
+  __device__ __forceinline__ void unpack(float (&o)[8]) const {
+    if constexpr (ESZ == 4) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { o[e] = __uint_as_float(a[e]); o[4 + e] = __uint_as_float(b[e]); }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { o[2 * e] = __uint_as_float(a[e] << 16); o[2 * e + 1] = __uint_as_float(a[e] & 0xffff0000u); }
+    }
+  }
+};
+
 // ds_read_b128 of a [rows][64 B] image is 2-way bank-conflicted for the 16x16x32 fragment
 // pattern (row = lane&15, chunk = lane>>4); XOR-ing the 16-byte chunk index with h[(row>>2)&3],
 // h = {0,2,3,1}, makes every 16-lane service group hit 16 distinct slots.
@@ -224,13 +242,19 @@ template <typename T> __device__ __forceinline__ float load_as_float(const void*
 // forward / dgrad / stem: BM x BN output tile, 4 waves as WM x WN, double-buffered LDS,
 // one barrier per K-chunk, global loads of chunk k+1 in flight under the MFMAs of chunk k.
 // ------------------------------------------------------------------------------------------
+// dynamic LDS bytes of a k_igemm launch: the prologue's per-channel tables (scale, shift[, gam]) over the Kc input channels
+static inline unsigned igemm_pro_lds(int pro, int Kc) { return pro ? (pro == 2 ? 3u : 2u) * (unsigned)Kc * 4u : 0u; }
+
 // MODE (gather geometry) and PRO (BN+ReLU prologue) are compile-time so the steady-state K loop is
 // straight-line code: hipcc then keeps counted s_waitcnt vmcnt(N) for the register ring.
 template <typename T, int BM, int BN, int WM, int WN, int MODE, int PRO, int EPI, bool ADD, int KC = 64, int PD = 3>   // PRO: 0 none, 1 BN+ReLU, 2 BN-backward affine; KC: bytes of the contraction axis per row and K-chunk; PD: ring depth
 // waves per SIMD the register budget must allow: 3 where the kernel fits 168 registers without spilling (measured:
 // +10-20 % on the prologue-free variants), 2 for the BN-prologue variants (they spill 35-50 registers at 3)
 // (WM x WN = 4 waves; or 8 waves on a 128x128 tile for launches with too few tiles to give every SIMD two waves)
-__global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN == 8 ? 4 : ((PRO == 0 && EPI != EPI_BNBWD_OUT && !ADD) ? 3 : 2))) void k_igemm(ConvArgs a) {
+#ifndef FRX_C1_OCC
+#define FRX_C1_OCC 3
+#endif
+__global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN == 8 ? 4 : ((PRO == 0 && EPI != EPI_BNBWD_OUT && !ADD) ? 3 : ((BM == 128 && BN == 64 && ADD && EPI == EPI_BNBWD_OUT) ? FRX_C1_OCC : 2)))) void k_igemm(ConvArgs a) {
   constexpr int VEC = TT<T>::VEC, CE = KC / (int)sizeof(T);      // elements per 16-byte load; elements per K-chunk
   constexpr int CPR = KC / 16;                                   // 16-byte slots per row of the LDS image
   constexpr int NT = 64 * WM * WN, RPP = NT / CPR;     // threads; tile rows staged per pass (CPR x 16-byte loads per row)
@@ -243,10 +267,12 @@ __global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN 
   __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
   // BN scale/shift of the input channels live in LDS: fetching them from global memory at commit
   // time would be the NEWEST vector-memory op and force vmcnt(0), draining the prefetch ring.
-  constexpr int PRO_MAXC = 2048;
-  __shared__ __attribute__((aligned(16))) float s_scale[PRO ? PRO_MAXC : 4];
-  __shared__ __attribute__((aligned(16))) float s_shift[PRO ? PRO_MAXC : 4];
-  __shared__ __attribute__((aligned(16))) float s_gam[PRO == 2 ? PRO_MAXC : 4];
+  // (dynamic LDS, igemm_pro_lds() bytes: sized by the layer's channel count -- a fixed 2048-channel table cost 24 KB,
+  // i.e. a resident block per CU, on the short-K layers)
+  extern __shared__ __attribute__((aligned(16))) float s_pro[];
+  float* const s_scale = s_pro;
+  float* const s_shift = s_pro + (PRO ? a.Kc : 0);
+  float* const s_gam = s_pro + (PRO == 2 ? 2 * a.Kc : 0);
 
   FRX_STAMP(0);
   // XCD-aware tile order: blocks that share an A row-panel (same mt) share an XCD's L2.
@@ -569,25 +595,27 @@ __global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN 
     // Issue every epilogue load of this channel pair first (up to 3 tensors x FM fragments in flight),
     // then consume: one memory round trip per pair instead of one per fragment.
     const unsigned eoff = elem0 + 32u * a2;                    // + i*rstep goes into the scalar offset
-    float av[ADD ? FM : 1][8], yv[(EPI == EPI_BNBWD || EPI == EPI_BNBWD_OUT) ? FM : 1][8], ov[EPI == EPI_BNBWD_OUT ? FM : 1][8];
+    // The loaded values stay PACKED (raw 16-byte registers, mask bits as one dword) until the row that uses them is
+    // consumed: unpacking on arrival kept 3 x FM x 8 floats live at once and cost the conv1-type kernel its occupancy.
+    constexpr bool EY = (EPI == EPI_BNBWD || EPI == EPI_BNBWD_OUT);
+    Raw8<OUT32 ? 4 : 2> avr[ADD ? FM : 1];
+    Raw8<sizeof(T)> yvr[EY ? FM : 1], ovr[EPI == EPI_BNBWD_OUT ? FM : 1];
+    unsigned obits[EPI == EPI_BNBWD_OUT ? FM : 1];
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
       // (row i of the tile: a scalar offset from the lane's first row -- or, in parity-class mode, its own vector offset)
       const int so_t = s2c ? 0 : (int)(i * rstep * sizeof(T));
       const unsigned eoff_i = s2c ? erow[i] + 32u * a2 : eoff;
-      if constexpr (ADD) buf_load8<OUT32 ? 4 : 2>(rsrcAdd, addvo[i] + 32u * a2 * OSZ, 0, av[i]);
-      if constexpr (EPI == EPI_BNBWD || EPI == EPI_BNBWD_OUT) buf_load8<sizeof(T)>(rsrcEy, eoff_i * (unsigned)sizeof(T), so_t, yv[i]);
+      if constexpr (ADD) avr[i].load(rsrcAdd, addvo[i] + 32u * a2 * OSZ, 0);
+      if constexpr (EY) yvr[i].load(rsrcEy, eoff_i * (unsigned)sizeof(T), so_t);
       if constexpr (EPI == EPI_BNBWD_OUT) {
-        if (ebits) {        // this lane's 8 channels are 8 / VEC groups: 1 mask byte (bf16) or 2 (fp32); expand to +-1
+        if (ebits) {        // this lane's 8 channels are 8 / VEC groups: 1 mask byte (bf16) or 2 (fp32)
           const unsigned gidx = (s2c ? eoff_i : eoff + (unsigned)i * rstep) / (unsigned)VEC;
-          unsigned m8;
-          if constexpr (VEC == 8) m8 = __builtin_amdgcn_raw_buffer_load_b8(rsrcEo, gidx, 0, 0);
-          else m8 = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rsrcEo, gidx, 0, 0) |
-                    ((unsigned)__builtin_amdgcn_raw_buffer_load_b8(rsrcEo, gidx + 1u, 0, 0) << 4);
-#pragma unroll
-          for (int e = 0; e < 8; ++e) ov[i][e] = ((m8 >> e) & 1u) ? 1.f : 0.f;
+          if constexpr (VEC == 8) obits[i] = __builtin_amdgcn_raw_buffer_load_b8(rsrcEo, gidx, 0, 0);
+          else obits[i] = (unsigned)__builtin_amdgcn_raw_buffer_load_b8(rsrcEo, gidx, 0, 0) |
+                          ((unsigned)__builtin_amdgcn_raw_buffer_load_b8(rsrcEo, gidx + 1u, 0, 0) << 4);
         } else {
-          buf_load8<sizeof(T)>(rsrcEo, eoff_i * (unsigned)sizeof(T), so_t, ov[i]);
+          ovr[i].load(rsrcEo, eoff_i * (unsigned)sizeof(T), so_t);
         }
       }
     }
@@ -597,21 +625,32 @@ __global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN 
       float v[8];
 #pragma unroll
       for (int e = 0; e < 8; ++e) v[e] = acc[i][2 * a2 + (e >> 2)][e & 3];
+      float yv_i[8];
+      if constexpr (EY) yvr[i].unpack(yv_i);
       if constexpr (EPI == EPI_FC) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] += bias[e];
       }
       if constexpr (ADD) {
+        float av_i[8];
+        avr[i].unpack(av_i);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += av[i][e];
+        for (int e = 0; e < 8; ++e) v[e] += av_i[e];
       }
       if constexpr (EPI == EPI_BNBWD_OUT) {
+        if (ebits) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = ov[i][e] > 0.f ? v[e] : 0.f;
+          for (int e = 0; e < 8; ++e) v[e] = ((obits[i] >> e) & 1u) ? v[e] : 0.f;
+        } else {
+          float ov_i[8];
+          ovr[i].unpack(ov_i);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = ov_i[e] > 0.f ? v[e] : 0.f;
+        }
       }
       if constexpr (EPI == EPI_BNBWD) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = fmaf(yv[i][e], esc[e], esh[e]) > 0.f ? v[e] : 0.f;
+        for (int e = 0; e < 8; ++e) v[e] = fmaf(yv_i[e], esc[e], esh[e]) > 0.f ? v[e] : 0.f;
       }
       if constexpr (OUT32) {
         u32x4_t s0, s1;
@@ -636,7 +675,7 @@ __global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN 
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           csum[2 * a2 + (e >> 2)][e & 3] += v[e];
-          csq[2 * a2 + (e >> 2)][e & 3] += v[e] * (yv[i][e] - emu[e]) * eis[e];
+          csq[2 * a2 + (e >> 2)][e & 3] += v[e] * (yv_i[e] - emu[e]) * eis[e];
         }
       }
     }

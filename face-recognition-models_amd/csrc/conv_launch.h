@@ -45,8 +45,12 @@ int launch_igemm_dgrad_bn(hipStream_t st, const ConvArgs& a, int dtype, TileCfg 
 int launch_wgrad(hipStream_t st, const WgradArgs& a, int dtype, int bt, int wmode, bool pro, bool ypro, int grid);
 int launch_wgrad_grouped(hipStream_t st, int dtype, const WgradArgs* layers, const WgradItem* items, int nitems);
 
+#ifndef FRX_C1_PD
+#define FRX_C1_PD 2
+#endif
+// (the conv1-type input gradient -- skip addend + merge-ReLU mask on the 128x64 tile -- runs its own ring depth)
 #define FRX_IGEMM_K(T_, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, ADD_, KC_) \
-  hipLaunchKernelGGL((k_igemm<T_, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, ADD_, KC_>), dim3(grid), dim3(64 * WM_ * WN_), 0, st, a)
+  hipLaunchKernelGGL((k_igemm<T_, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, ADD_, KC_, ((BM_) == 128 && (BN_) == 64 && (ADD_) && (EPI_) == EPI_BNBWD_OUT) ? FRX_C1_PD : 3>), dim3(grid), dim3(64 * WM_ * WN_), igemm_pro_lds(PRO_, a.Kc), st, a)
 #define FRX_IGEMM_LAUNCH64(T_, MODE_, PRO_, EPI_, ADD_)                                                                    \
   do {                                                                                                                     \
     if (c.bm == 128 && c.bn == 128) FRX_IGEMM_K(T_, 128, 128, 2, 4, MODE_, PRO_, EPI_, ADD_, 64);                           \
