@@ -293,8 +293,8 @@ extern "C" int64_t frx_wgrad_group_bytes(const frx_wgrad_job* jobs, int njobs) {
 }
 
 extern "C" int frx_wgrad_group_plan(int device, frx_stream_t stream, const frx_wgrad_job* jobs, int njobs, void* table_host,
-                                    void* table_dev, int64_t table_bytes, int* nitems) {
-  FRX_CHECK_ARG(table_host && table_dev && nitems, "wgrad_group_plan: NULL pointer");
+                                    void* table_dev, int64_t table_bytes, int* nitems, int* small_tiles) {
+  FRX_CHECK_ARG(table_host && table_dev && nitems && small_tiles, "wgrad_group_plan: NULL pointer");
   std::vector<WgradArgs> layers; std::vector<WgradItem> items;
   const int n = group_build(jobs, njobs, &layers, &items);
   if (n < 0) return n;
@@ -309,15 +309,18 @@ extern "C" int frx_wgrad_group_plan(int device, frx_stream_t stream, const frx_w
   memcpy((char*)table_host + off, items.data(), items.size() * sizeof(WgradItem));
   FRX_HIP(hipMemcpyAsync(table_dev, table_host, need, hipMemcpyHostToDevice, (hipStream_t)stream));
   *nitems = (int)items.size();
+  *small_tiles = 1;
+  for (const WgradArgs& a : layers) if (a.variant & WGV_BT128) *small_tiles = 0;
   return FRX_OK;
 }
 
-extern "C" int frx_wgrad_group_run(int device, frx_stream_t stream, int dtype, const void* table_dev, int njobs, int nitems) {
+extern "C" int frx_wgrad_group_run(int device, frx_stream_t stream, int dtype, const void* table_dev, int njobs, int nitems,
+                                   int small_tiles) {
   FRX_CHECK_ARG(dtype == FRX_F32 || dtype == FRX_BF16, "wgrad_group_run: dtype");
   FRX_CHECK_ARG(table_dev && njobs > 0 && nitems > 0, "wgrad_group_run: bad args");
   FRX_ENTER(device);
   return launch_wgrad_grouped((hipStream_t)stream, dtype, (const WgradArgs*)table_dev,
-                              (const WgradItem*)((const char*)table_dev + group_items_offset(njobs)), nitems);
+                              (const WgradItem*)((const char*)table_dev + group_items_offset(njobs)), nitems, small_tiles != 0);
 }
 
 extern "C" int frx_conv_wgrad(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x,

@@ -1065,9 +1065,11 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
 struct WgradItem { int layer, split, tile, tap; };
 enum { WGV_BT128 = 1, WGV_GENERAL = 2, WGV_STEM = 4, WGV_PRO = 8, WGV_YPRO = 16 };   // WgradArgs::variant bits
 
-template <typename T>
-__global__ __launch_bounds__(256, 2) void k_wgrad_grouped(const WgradArgs* __restrict__ layers,
-                                                          const WgradItem* __restrict__ items, int nitems) {
+// SMALL: a list whose layers all take the 64 x 64 tile (layer1 and the stem: the HBM-bound end of the network) gets its own
+// instantiation -- under 128 registers, four blocks per CU -- instead of the register budget of the widest 128 x 128 variant.
+template <typename T, bool SMALL>
+__global__ __launch_bounds__(256, SMALL ? 4 : 2) void k_wgrad_grouped(const WgradArgs* __restrict__ layers,
+                                                                      const WgradItem* __restrict__ items, int nitems) {
   __shared__ __attribute__((aligned(16))) char smem[WGRAD_SMEM];
   for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
     const WgradItem w = items[it];
@@ -1079,8 +1081,9 @@ __global__ __launch_bounds__(256, 2) void k_wgrad_grouped(const WgradArgs* __res
     const int v = __builtin_amdgcn_readfirstlane(a.variant);
 #define FRX_WGV(BT_, WM_, PRO_, YP_) wgrad_block<T, BT_, WM_, PRO_, YP_>(a, split, tile, tap, smem)
     if (v & WGV_STEM) FRX_WGV(64, WG_STEM, false, false);
-    else if (v & WGV_BT128) {
-      if ((v & WGV_GENERAL) && (v & WGV_YPRO)) { if (v & WGV_PRO) FRX_WGV(128, WG_GENERAL, true, true); else FRX_WGV(128, WG_GENERAL, false, true); }
+    else if (!SMALL && (v & WGV_BT128)) {
+      if constexpr (SMALL) {}
+      else if ((v & WGV_GENERAL) && (v & WGV_YPRO)) { if (v & WGV_PRO) FRX_WGV(128, WG_GENERAL, true, true); else FRX_WGV(128, WG_GENERAL, false, true); }
       else if (v & WGV_GENERAL) { if (v & WGV_PRO) FRX_WGV(128, WG_GENERAL, true, false); else FRX_WGV(128, WG_GENERAL, false, false); }
       else if (v & WGV_YPRO) { if (v & WGV_PRO) FRX_WGV(128, WG_POINTWISE, true, true); else FRX_WGV(128, WG_POINTWISE, false, true); }
       else { if (v & WGV_PRO) FRX_WGV(128, WG_POINTWISE, true, false); else FRX_WGV(128, WG_POINTWISE, false, false); }

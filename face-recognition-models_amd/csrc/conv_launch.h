@@ -43,7 +43,7 @@ int launch_igemm_dgrad_plain(hipStream_t st, const ConvArgs& a, int dtype, TileC
 int launch_igemm_dgrad_bn(hipStream_t st, const ConvArgs& a, int dtype, TileCfg c, int grid, int epi, bool add);
 
 int launch_wgrad(hipStream_t st, const WgradArgs& a, int dtype, int bt, int wmode, bool pro, bool ypro, int grid);
-int launch_wgrad_grouped(hipStream_t st, int dtype, const WgradArgs* layers, const WgradItem* items, int nitems);
+int launch_wgrad_grouped(hipStream_t st, int dtype, const WgradArgs* layers, const WgradItem* items, int nitems, bool small_tiles);
 
 #ifndef FRX_C1_PD
 #define FRX_C1_PD 2

@@ -19,15 +19,21 @@ int launch_wgrad(hipStream_t st, const WgradArgs& a, int dtype, int bt, int wmod
   FRX_LAUNCH_CHECK();
   return FRX_OK;
 }
-// persistent blocks: two per CU (the register budget of the widest variant), fewer when the list is short
-int launch_wgrad_grouped(hipStream_t st, int dtype, const WgradArgs* layers, const WgradItem* items, int nitems) {
-  const char* e = getenv("FRX_WGRAD_GROUP_BLOCKS");
-  int grid = e ? atoi(e) : 512;
+// persistent blocks: two per CU (the register budget of the widest variant) -- four for a list of 64 x 64-tile layers only --
+// fewer when the list is short
+int launch_wgrad_grouped(hipStream_t st, int dtype, const WgradArgs* layers, const WgradItem* items, int nitems, bool small_tiles) {
+  const char* e = getenv(small_tiles ? "FRX_WGRAD_GROUP_BLOCKS_SMALL" : "FRX_WGRAD_GROUP_BLOCKS");
+  int grid = e ? atoi(e) : (small_tiles ? 1024 : 512);
   if (grid > nitems) grid = nitems;
   grid = grid / 8 * 8;
   if (grid < 8) grid = 8;
-  if (dtype == FRX_BF16) hipLaunchKernelGGL(k_wgrad_grouped<bf16_t>, dim3(grid), dim3(256), 0, st, layers, items, nitems);
-  else hipLaunchKernelGGL(k_wgrad_grouped<float>, dim3(grid), dim3(256), 0, st, layers, items, nitems);
+  if (dtype == FRX_BF16) {
+    if (small_tiles) hipLaunchKernelGGL((k_wgrad_grouped<bf16_t, true>), dim3(grid), dim3(256), 0, st, layers, items, nitems);
+    else hipLaunchKernelGGL((k_wgrad_grouped<bf16_t, false>), dim3(grid), dim3(256), 0, st, layers, items, nitems);
+  } else {
+    if (small_tiles) hipLaunchKernelGGL((k_wgrad_grouped<float, true>), dim3(grid), dim3(256), 0, st, layers, items, nitems);
+    else hipLaunchKernelGGL((k_wgrad_grouped<float, false>), dim3(grid), dim3(256), 0, st, layers, items, nitems);
+  }
   FRX_LAUNCH_CHECK();
   return FRX_OK;
 }

@@ -440,6 +440,7 @@ class ResNet50Engine:
         self._backward_blocks(self.SPLIT_BLOCK - 1, 0)
         self._backward_stem()
         self._run_wgrad_group(1)
+        self._run_wgrad_group(2)
 
     def _backward_blocks(self, hi, lo):
         N, dt = self.N, self.dtype
@@ -534,11 +535,12 @@ class ResNet50Engine:
             ops.conv_wgrad(c.desc, x, dy, j["dw"], **kw)
 
     def _plan_wgrad_groups(self):
-        """Two work lists of persistent-block weight-gradient items: [upper blocks] and [lower blocks + stem]
-        (data-parallel training all-reduces the upper gradients while the lower backward still runs)."""
-        groups = [[], []]
+        """Three work lists of persistent-block weight-gradient items: [upper blocks] (data-parallel training all-reduces
+        the upper gradients while the lower backward still runs), [layer2] and [layer1 + stem] -- the last one holds only
+        64 x 64-tile layers, which frx_wgrad_group_run then runs four blocks per CU instead of two."""
+        groups = [[], [], []]
         for bi, b in enumerate(self.blocks):
-            jobs = groups[0] if bi >= self.SPLIT_BLOCK else groups[1]
+            jobs = groups[0] if bi >= self.SPLIT_BLOCK else (groups[1] if bi >= LAYERS[0] else groups[2])
             x_in = self.blocks[bi - 1].out if bi > 0 else self.pool_out
             C3, C2, C1, CD = b.coefs
             for c, x, xb, dz, coef in ((b.conv3, b.conv2.y, b.conv2, b.dz3, C3), (b.down, x_in, None, b.dz3, CD),
@@ -550,7 +552,7 @@ class ResNet50Engine:
                 else:
                     jobs.append(self._wgrad_job(c, x, dz, x_bn=xb, pro_y=c.y, pro_coef=coef))
             jobs.append(self._wgrad_job(b.conv2, b.conv1.y, b.dy2, x_bn=b.conv1))
-        groups[1].append(self._wgrad_job(self.stem, self.xin, self.dy_stem))
+        groups[2].append(self._wgrad_job(self.stem, self.xin, self.dy_stem))
         self._wg_groups = [ops.wgrad_group_plan(self.dtype, jobs) for jobs in groups]
 
     def _run_wgrad_group(self, which):

@@ -334,7 +334,7 @@ def conv_wgrad(d, x, dy, dw, in_scale=None, in_shift=None, in_relu=False):
 
 class WgradGroup:
     """a planned frx_wgrad_group table (device) plus everything that must outlive it"""
-    __slots__ = ("table", "njobs", "nitems", "dtype", "flops", "nbytes", "keep")
+    __slots__ = ("table", "njobs", "nitems", "small_tiles", "dtype", "flops", "nbytes", "keep")
 
 
 def wgrad_group_plan(dtype, jobs):
@@ -354,10 +354,10 @@ def wgrad_group_plan(dtype, jobs):
     # the table is assembled in pinned host memory and copied by one stream-ordered asynchronous copy (enqueue-only,
     # like every libfrx call); the host image has to outlive that copy, so it stays with the group
     host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
-    n = C.c_int(0)
+    n, small = C.c_int(0), C.c_int(0)
     check(_lib.lib().frx_wgrad_group_plan(_dev(g.table), _stream(g.table), arr, len(jobs), C.c_void_p(host.data_ptr()),
-                                          _p(g.table), nbytes, C.byref(n)), "frx_wgrad_group_plan")
-    g.njobs, g.nitems, g.dtype = len(jobs), n.value, dtype
+                                          _p(g.table), nbytes, C.byref(n), C.byref(small)), "frx_wgrad_group_plan")
+    g.njobs, g.nitems, g.small_tiles, g.dtype = len(jobs), n.value, small.value, dtype
     g.flops = sum(conv_flops(j["d"]) for j in jobs)
     g.nbytes = sum(conv_bytes(j["d"], n_out=2 if j.get("pro_y") is not None else 1, wbytes=j["dw"].numel() * 4) for j in jobs)
     g.keep = [t for j in jobs for t in j.values() if isinstance(t, torch.Tensor)] + [host]
@@ -366,8 +366,8 @@ def wgrad_group_plan(dtype, jobs):
 
 def wgrad_group_run(g):
     _timed(f"k_wgrad_grouped<{_dt_name(g.dtype)}>", g.flops, g.table, lambda: check(
-        _lib.lib().frx_wgrad_group_run(_dev(g.table), _stream(g.table), g.dtype, _p(g.table), g.njobs, g.nitems),
-        "frx_wgrad_group_run"), nbytes=g.nbytes)
+        _lib.lib().frx_wgrad_group_run(_dev(g.table), _stream(g.table), g.dtype, _p(g.table), g.njobs, g.nitems,
+                                       g.small_tiles), "frx_wgrad_group_run"), nbytes=g.nbytes)
 
 
 def conv_dgrad_stat_rows(d):

@@ -252,10 +252,14 @@ typedef struct frx_wgrad_job {
 } frx_wgrad_job;
 int64_t frx_wgrad_group_bytes(const frx_wgrad_job* jobs, int njobs);          /* size of the device table; < 0: error */
 /* Enqueue-only like every other call: the table is built in `table_host` (table_bytes of PINNED host memory owned by the
- * caller, to be kept alive until the copy has run) and copied to `table_dev` by ONE asynchronous copy on `stream`. */
+ * caller, to be kept alive until the copy has run) and copied to `table_dev` by ONE asynchronous copy on `stream`.
+ * *small_tiles <- 1 when every job takes the 64 x 64 tile (Co <= 64 or Ci <= 64: layer1, the stem): hand it to
+ * frx_wgrad_group_run, which then launches the instantiation that fits four persistent blocks per CU instead of two --
+ * so group such layers into a list of their own. */
 int frx_wgrad_group_plan(int device, frx_stream_t stream, const frx_wgrad_job* jobs, int njobs, void* table_host,
-                         void* table_dev, int64_t table_bytes, int* nitems);
-int frx_wgrad_group_run(int device, frx_stream_t stream, int dtype, const void* table_dev, int njobs, int nitems);
+                         void* table_dev, int64_t table_bytes, int* nitems, int* small_tiles);
+int frx_wgrad_group_run(int device, frx_stream_t stream, int dtype, const void* table_dev, int njobs, int nitems,
+                        int small_tiles);
 
 /* ---------------------------------------------------------------- backbone: BatchNorm / ReLU / residual / pools
  * Replace nn.BatchNorm2d x53 (train: batch statistics + running-stat update, momentum 0.1, eps 1e-5;
