@@ -254,7 +254,10 @@ template <typename T, int BM, int BN, int WM, int WN, int MODE, int PRO, int EPI
 #ifndef FRX_C1_OCC
 #define FRX_C1_OCC 3
 #endif
-__global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN == 8 ? 4 : ((PRO == 0 && EPI != EPI_BNBWD_OUT && !ADD) ? 3 : ((BM == 128 && BN == 64 && ADD && EPI == EPI_BNBWD_OUT) ? FRX_C1_OCC : 2)))) void k_igemm(ConvArgs a) {
+#ifndef FRX_OCC4W            // tuning aid: blocks per CU the four-wave tiles are compiled for (0: the table below)
+#define FRX_OCC4W 0
+#endif
+__global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN == 8 ? 4 : (FRX_OCC4W ? FRX_OCC4W : ((PRO == 0 && EPI != EPI_BNBWD_OUT && !ADD) ? 3 : ((BM == 128 && BN == 64 && ADD && EPI == EPI_BNBWD_OUT) ? FRX_C1_OCC : 2))))) void k_igemm(ConvArgs a) {
   constexpr int VEC = TT<T>::VEC, CE = KC / (int)sizeof(T);      // elements per 16-byte load; elements per K-chunk
   constexpr int CPR = KC / 16;                                   // 16-byte slots per row of the LDS image
   constexpr int NT = 64 * WM * WN, RPP = NT / CPR;     // threads; tile rows staged per pass (CPR x 16-byte loads per row)
@@ -268,11 +271,11 @@ __global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN 
   // BN scale/shift of the input channels live in LDS: fetching them from global memory at commit
   // time would be the NEWEST vector-memory op and force vmcnt(0), draining the prefetch ring.
   // (dynamic LDS, igemm_pro_lds() bytes: sized by the layer's channel count -- a fixed 2048-channel table cost 24 KB,
-  // i.e. a resident block per CU, on the short-K layers)
+  // i.e. a resident block per CU, on the short-K layers.  Layout [channel / VEC][table][VEC]: the NTAB vectors of one
+  // 16-byte channel group sit next to each other, so one address register with immediate offsets reaches all of them,
+  // as the fixed-size tables allowed.)
   extern __shared__ __attribute__((aligned(16))) float s_pro[];
-  float* const s_scale = s_pro;
-  float* const s_shift = s_pro + (PRO ? a.Kc : 0);
-  float* const s_gam = s_pro + (PRO == 2 ? 2 * a.Kc : 0);
+  constexpr int NTAB = PRO == 2 ? 3 : 2;
 
   FRX_STAMP(0);
   // XCD-aware tile order: blocks that share an A row-panel (same mt) share an XCD's L2.
@@ -350,8 +353,9 @@ __global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN 
 
   if constexpr (PRO != 0) {
     for (int c = tid; c < a.Kc; c += NT) {
-      s_scale[c] = a.in_scale[c]; s_shift[c] = a.in_shift[c];
-      if constexpr (PRO == 2) s_gam[c] = a.pro_gam[c];
+      float* t = s_pro + (c / VEC) * (NTAB * VEC) + (c % VEC);
+      t[0] = a.in_scale[c]; t[VEC] = a.in_shift[c];
+      if constexpr (PRO == 2) t[2 * VEC] = a.pro_gam[c];
     }
     __syncthreads();
   }
@@ -429,10 +433,10 @@ __global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN 
     for (int i = 0; i < ALD; ++i) {
       uint4 v = ra[slot][i];
       if constexpr (PRO == 1)
-        v = bn_relu_vec<T>(v, s_scale + rc0[slot] + chunk * VEC, s_shift + rc0[slot] + chunk * VEC, a.in_relu);
+        v = bn_relu_vec<T>(v, s_pro + (rc0[slot] + chunk * VEC) * NTAB, s_pro + (rc0[slot] + chunk * VEC) * NTAB + VEC, a.in_relu);
       if constexpr (PRO == 2)
-        v = affine2_vec<T>(v, ra2[slot][i], s_scale + rc0[slot] + chunk * VEC, s_shift + rc0[slot] + chunk * VEC,
-                           s_gam + rc0[slot] + chunk * VEC);
+        v = affine2_vec<T>(v, ra2[slot][i], s_pro + (rc0[slot] + chunk * VEC) * NTAB, s_pro + (rc0[slot] + chunk * VEC) * NTAB + VEC,
+                           s_pro + (rc0[slot] + chunk * VEC) * NTAB + 2 * VEC);
       if constexpr (PRO != 0) {      // out-of-range loads are already 0; a prologue would turn them into f(0)
         if (!((rmask[slot] >> i) & 1u)) v = make_uint4(0, 0, 0, 0);
       }

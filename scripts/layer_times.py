@@ -3,7 +3,9 @@ import sys, os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "face-recognition-models_amd"))
 import torch
-from frx import engine as E, ops
+from frx import engine as E, ops, _lib
+if os.environ.get("FRX_LIB"):          # A/B builds
+    _lib.load_library(os.path.join(ROOT, os.environ["FRX_LIB"]))
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 eng = E.FaceEngine("arcface", 10575, N, dtype=ops.BF16, device="cuda:0", seed=0)
 g = torch.Generator().manual_seed(0)
