@@ -18,13 +18,9 @@ static int launch_igemm(hipStream_t st, ConvArgs a, int dtype) {
   FRX_CHECK_ARG(xb < 0x80000000ull && wb < 0x80000000ull && yb < 0x80000000ull,
                 "igemm: tensors must stay below 2 GiB (32-bit buffer offsets)");
   a.xbytes = (unsigned)xb; a.wbytes = (unsigned)wb;
-  TileCfg c = pick_tile(a.M, a.Ncol, a.mode == MODE_STEM, a.mode != MODE_DGRAD);
+  const bool pointwise = a.mode != MODE_STEM && a.R == 1 && a.S == 1 && a.stride == 1;
+  TileCfg c = pick_tile(a.M, a.Ncol, (long)a.R * a.S * a.Kc, pointwise, a.mode != MODE_STEM && !a.s2c);
   if (a.Ncol % c.bn != 0) c = TileCfg{c.bm, 64, 4, 64};
-  // conv1-type input gradients (narrow contraction, three full-width tensors in the epilogue: addend, masked BN input,
-  // output): the 128x64 four-wave tile -- twice the blocks, three resident per CU -- interleaves the epilogues' memory
-  // phases better than two eight-wave blocks (scripts/fused_ab.py on HBM-resident data: 130 -> 107 us at 56x56,
-  // 76 -> 61 us at 28x28, 55 -> 49 us at 14x14)
-  if (a.mode == MODE_DGRAD && a.epi_bnbwd && a.addend && c.bm == 128 && c.bn == 128 && !getenv("FRX_IGEMM_TILE")) c = TileCfg{128, 64, 4, 64};
   FRX_CHECK_ARG(c.kc == 64 || (a.Kc * (int)esz) % c.kc == 0, "igemm: %d channels do not fill %d-byte K-chunks", a.Kc, c.kc);
   a.tilesM = cdiv(a.M, c.bm);
   if (a.s2c) {                     // tiles per parity class (h & 1, w & 1), class-major
@@ -77,7 +73,25 @@ using namespace frx;
 extern "C" int frx_conv_stat_rows(const frx_conv_desc* d) {
   if (check_conv(d) != FRX_OK) return -1;
   const long M = (long)d->N * d->Ho * d->Wo;
-  return cdiv(M, pick_tile(M, d->Co, d->stem != 0, true).bm);
+  return cdiv(M, pick_tile(M, d->Co, (long)d->R * d->S * d->Ci, d->R == 1 && d->S == 1 && d->stride == 1, !d->stem).bm);
+}
+
+// Diagnostic: the block tile frx_conv_fwd (dgrad = 0) or frx_conv_dgrad* (dgrad = 1) launches for this layer.
+extern "C" int frx_conv_tile(const frx_conv_desc* d, int dgrad, int* bm, int* bn) {
+  if (int rc = check_conv(d)) return rc;
+  FRX_CHECK_ARG(bm && bn, "conv_tile: NULL pointer");
+  const bool pw = d->R == 1 && d->S == 1 && d->stride == 1;
+  TileCfg c;
+  if (dgrad) {
+    const bool s2c = d->stride == 2 && (d->R > 1 || d->S > 1) && !getenv("FRX_DGRAD_NO_S2C");
+    c = pick_tile((long)d->N * d->Hi * d->Wi, d->Ci, (long)d->R * d->S * d->Co, pw, !s2c);
+    if (d->Ci % c.bn != 0) c.bn = 64;
+  } else {
+    c = pick_tile((long)d->N * d->Ho * d->Wo, d->Co, (long)d->R * d->S * d->Ci, pw, !d->stem);
+    if (d->Co % c.bn != 0) c.bn = 64;
+  }
+  *bm = c.bm; *bn = c.bn;
+  return FRX_OK;
 }
 
 extern "C" int frx_stem_padded_dims(int Hi, int Wi, int* Hp, int* Wp) {
@@ -176,8 +190,9 @@ extern "C" int frx_conv_dgrad_bn(int device, frx_stream_t stream, const frx_conv
 extern "C" int frx_conv_dgrad_stat_rows(const frx_conv_desc* d) {
   if (check_conv(d) != FRX_OK) return -1;
   const long M = (long)d->N * d->Hi * d->Wi;
-  const int bm = pick_tile(M, d->Ci, false, false).bm;
-  if (d->stride == 2 && (d->R > 1 || d->S > 1)) {       // parity-class tiles (launch_igemm)
+  const bool s2c = d->stride == 2 && (d->R > 1 || d->S > 1) && !getenv("FRX_DGRAD_NO_S2C");
+  const int bm = pick_tile(M, d->Ci, (long)d->R * d->S * d->Co, d->R == 1 && d->S == 1 && d->stride == 1, !s2c).bm;
+  if (s2c) {                                             // parity-class tiles (launch_igemm)
     int t = 0;
     for (int cls = 0; cls < 4; ++cls) t += cdiv((long)d->N * ((d->Hi - (cls >> 1) + 1) / 2) * ((d->Wi - (cls & 1) + 1) / 2), bm);
     return t;

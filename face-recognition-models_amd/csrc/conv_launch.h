@@ -19,20 +19,28 @@ static inline bool tile_from_env(TileCfg* c) {
   return true;
 }
 
-// `fwd`: forward / stem (operand A = activations); false: input gradient
-static inline TileCfg pick_tile(long M, int Ncol, bool stem = false, bool fwd = true) {
+// Block tile of one implicit-GEMM launch: M x Ncol outputs, contraction K = taps x channels.  `pointwise`: 1x1, stride 1
+// (rows are whole pixels, no gather); `kc128_ok`: the launch can take 128-byte K-chunks (not the stem, not the
+// parity-class input gradients).  A pure function of the layer geometry: frx_conv_stat_rows / frx_conv_dgrad_stat_rows
+// (the partial-statistics rows = M tiles) go through it as well.  Measured per ResNet-50 shape on whole training steps
+// (scripts/layer_times.py under FRX_IGEMM_TILE, scripts/lt_compare.py).
+static inline TileCfg pick_tile(long M, int Ncol, long K, bool pointwise, bool kc128_ok) {
   TileCfg c;
-  if (tile_from_env(&c) && Ncol % c.bn == 0 && !(stem && c.kc != 64)) return c;
+  if (tile_from_env(&c) && Ncol % c.bn == 0 && !(!kc128_ok && c.kc != 64)) return c;
   if (Ncol <= 64) return {128, 64, 4, 64};
-  // measured per ResNet-50 shape (scripts/tile_ab.py): the square 128x128 tile wins down to ~3/4 of a wave of
-  // blocks (twice the MFMA work per staged byte and per prologue evaluation).  It runs EIGHT waves (2x4, 64x32 each):
-  // half the staging work and accumulators per wave keep it under 128 registers, i.e. 16 waves per CU instead of 8.
+  const long t64x128 = (kc128_ok && Ncol % 128 == 0) ? ((M + 63) / 64) * (Ncol / 128) : 0;
+  // deep pointwise contractions over few column tiles (layer3/4 conv1 forward, conv3 input gradients, layer4's
+  // projection): 64 pixels x 128 channels on four waves side by side with 128-byte K-chunks -- whole 128-byte lines of
+  // the activation rows, every wave sharing the one pixel tile (e.g. 256<-1024 at 14x14: 36 -> 31 us, 512<-2048 at
+  // 7x7: 48 -> 35 us, 1024->256 forward: 22.9 -> 20.4 us)
+  if (pointwise && K >= 1024 && t64x128 >= 192 && t64x128 <= 512) return {64, 128, 4, 128};
+  // otherwise the square 128x128 tile wins down to ~3/4 of a wave of blocks (twice the MFMA work per staged byte and
+  // per prologue evaluation).  It runs EIGHT waves (2x4, 64x32 each): half the staging work and accumulators per wave
+  // keep it under 128 registers, i.e. 16 waves per CU instead of 8.
   const long mt128 = (M + 127) / 128;
   if (mt128 * ((Ncol + 127) / 128) >= 192) return {128, 128, 8, 64};
-  // fewer tiles than that (layer4, M = 4096): forward convs take 64 pixels x 128 channels on four waves side by side
-  // (1x4) with 128-byte K-chunks -- the activation rows are read in whole 128-byte lines and every wave shares the one
-  // pixel tile (3x3 57 -> 48 us, 2048->512 33 -> 28 us); the input gradients stay on the 64x64 tile (measured equal or better)
-  if (fwd && Ncol % 128 == 0 && ((M + 63) / 64) * (Ncol / 128) >= 192) return {64, 128, 4, 128};
+  // fewer tiles than that (layer4, M = 4096): the 64x128 tile again (3x3 forward 57 -> 48 us, 3x3 input gradient 50 -> 46 us)
+  if (t64x128 >= 192) return {64, 128, 4, 128};
   return {64, 64, 4, 64};
 }
 
@@ -45,12 +53,8 @@ int launch_igemm_dgrad_bn(hipStream_t st, const ConvArgs& a, int dtype, TileCfg 
 int launch_wgrad(hipStream_t st, const WgradArgs& a, int dtype, int bt, int wmode, bool pro, bool ypro, int grid);
 int launch_wgrad_grouped(hipStream_t st, int dtype, const WgradArgs* layers, const WgradItem* items, int nitems, bool small_tiles);
 
-#ifndef FRX_C1_PD
-#define FRX_C1_PD 2
-#endif
-// (the conv1-type input gradient -- skip addend + merge-ReLU mask on the 128x64 tile -- runs its own ring depth)
 #define FRX_IGEMM_K(T_, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, ADD_, KC_) \
-  hipLaunchKernelGGL((k_igemm<T_, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, ADD_, KC_, ((BM_) == 128 && (BN_) == 64 && (ADD_) && (EPI_) == EPI_BNBWD_OUT) ? FRX_C1_PD : 3>), dim3(grid), dim3(64 * WM_ * WN_), igemm_pro_lds(PRO_, a.Kc), st, a)
+  hipLaunchKernelGGL((k_igemm<T_, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, ADD_, KC_>), dim3(grid), dim3(64 * WM_ * WN_), igemm_pro_lds(PRO_, a.Kc), st, a)
 #define FRX_IGEMM_LAUNCH64(T_, MODE_, PRO_, EPI_, ADD_)                                                                    \
   do {                                                                                                                     \
     if (c.bm == 128 && c.bn == 128) FRX_IGEMM_K(T_, 128, 128, 2, 4, MODE_, PRO_, EPI_, ADD_, 64);                           \

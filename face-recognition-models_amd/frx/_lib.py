@@ -69,6 +69,7 @@ _SIGS = {
     "frx_conv_dgrad": (C.c_int, [C.c_int, _P, C.POINTER(ConvDesc), _P, _P, _P, _P]),
     "frx_conv_wgrad": (C.c_int, [C.c_int, _P, C.POINTER(ConvDesc), _P, _P, _P, C.c_int, _P, _P]),
     "frx_conv_dgrad_stat_rows": (C.c_int, [C.POINTER(ConvDesc)]),
+    "frx_conv_tile": (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "frx_wgrad_group_bytes": (C.c_int64, [C.POINTER(WgradJob), C.c_int]),
     "frx_wgrad_group_plan": (C.c_int, [C.c_int, _P, C.POINTER(WgradJob), C.c_int, _P, _P, C.c_int64, C.POINTER(C.c_int),
                                        C.POINTER(C.c_int)]),

@@ -32,16 +32,11 @@ def _timed(label, flops, dev_tensor, fn, nbytes=0):
     return r
 
 
-def _igemm_tile(M, ncol, fwd=True):
-    """mirror of pick_tile() in csrc/conv_launch.h (only used to label profiled launches)"""
-    if ncol <= 64:
-        return 128, 64
-    mt = (M + 127) // 128
-    if mt * ((ncol + 127) // 128) >= 192:
-        return 128, 128
-    if fwd and ncol % 128 == 0 and ((M + 63) // 64) * (ncol // 128) >= 192:
-        return 64, 128
-    return 64, 64
+def _igemm_tile(d, dgrad=False):
+    """block tile of the launch, for the profiling labels (frx_conv_tile: the library's own choice)"""
+    bm, bn = C.c_int(0), C.c_int(0)
+    check(_lib.lib().frx_conv_tile(C.byref(d), int(dgrad), C.byref(bm), C.byref(bn)), "frx_conv_tile")
+    return bm.value, bn.value
 
 
 def _dt_name(dt):
@@ -307,7 +302,7 @@ def conv_flops(d):
 
 
 def conv_fwd(d, x, w, y, in_scale=None, in_shift=None, in_relu=False, bias=None, out_f32=False, stat_partial=None):
-    bm, bn = _igemm_tile(d.N * d.Ho * d.Wo, d.Co)
+    bm, bn = _igemm_tile(d) if PROFILER is not None else (0, 0)
     _timed(f"k_igemm<{_dt_name(d.dtype)},{bm},{bn}>", conv_flops(d), x, lambda: check(
         _lib.lib().frx_conv_fwd(_dev(x), _stream(x), C.byref(d), _p(x), _p(w), _p(in_scale), _p(in_shift),
                                 int(in_relu), _p(bias), _p(y), int(out_f32), _p(stat_partial)), "frx_conv_fwd"),
@@ -316,7 +311,7 @@ def conv_fwd(d, x, w, y, in_scale=None, in_shift=None, in_relu=False, bias=None,
 
 
 def conv_dgrad(d, dy, w_crsk, dx, addend=None):
-    bm, bn = _igemm_tile(d.N * d.Hi * d.Wi, d.Ci, fwd=False)
+    bm, bn = _igemm_tile(d, True) if PROFILER is not None else (0, 0)
     _timed(f"k_igemm<{_dt_name(d.dtype)},{bm},{bn}>", conv_flops(d), dy, lambda: check(
         _lib.lib().frx_conv_dgrad(_dev(dy), _stream(dy), C.byref(d), _p(dy), _p(w_crsk), _p(addend), _p(dx)),
         "frx_conv_dgrad"), nbytes=conv_bytes(d, n_in=1 + (addend is not None)))
@@ -385,9 +380,7 @@ def conv_dgrad_bn(d, dz, w_crsk, dx, addend=None, pro_y=None, pro_coef=None, epi
     f = _lib.DgradFuse(*[0 if t is None else t.data_ptr() for t in
                          (pro_y, pro_coef, epi_y, epi_out, epi_scale, epi_shift, epi_mean, epi_invstd, epi_partial, epi_out_bits)],
                        int(addend_stride), 0 if pro_dy_out is None else pro_dy_out.data_ptr())
-    bm, bn = _igemm_tile(d.N * d.Hi * d.Wi, d.Ci, fwd=False)
-    if (bm, bn) == (128, 128) and addend is not None and epi_y is not None:
-        bn = 64                      # conv1-type input gradients take the 128x64 tile (launch_igemm in csrc/conv.hip)
+    bm, bn = _igemm_tile(d, True) if PROFILER is not None else (0, 0)
     _timed(f"k_igemm<{_dt_name(d.dtype)},{bm},{bn}>", conv_flops(d), dz, lambda: check(
         _lib.lib().frx_conv_dgrad_bn(_dev(dz), _stream(dz), C.byref(d), _p(dz), _p(w_crsk), _p(addend), _p(dx),
                                      C.byref(f)), "frx_conv_dgrad_bn"),

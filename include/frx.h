@@ -194,6 +194,9 @@ typedef struct frx_conv_desc {
 
 /* rows of the stat_partial buffer ([rows][2][Co] floats) frx_conv_fwd writes for this layer */
 int frx_conv_stat_rows(const frx_conv_desc* d);
+/* diagnostic (host logic only): the block tile (pixels x channels) frx_conv_fwd (dgrad = 0) or frx_conv_dgrad* (dgrad = 1)
+ * launches for this layer -- what the profiling labels and the stat-row counts are derived from */
+int frx_conv_tile(const frx_conv_desc* d, int dgrad, int* bm, int* bn);
 int frx_stem_padded_dims(int Hi, int Wi, int* Hp, int* Wp);
 /* y = conv(f(x), w) [+ bias]; out_f32 stores y as fp32 (the fc layer feeding the head) */
 int frx_conv_fwd(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x, const void* w_krsc,

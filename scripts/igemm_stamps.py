@@ -36,7 +36,7 @@ for (Ci, Co, k, st, Hi) in SH:
     fn = lambda: ops.conv_fwd(d, x, w, y, in_scale=sc, in_shift=sh, in_relu=True, stat_partial=part)
     us = timeit(fn)
     M = N * d.Ho * d.Wo
-    bm, bn = ops._igemm_tile(M, Co)
+    bm, bn = ops._igemm_tile(d)
     nb = ((-(-M // bm) + 7) // 8 * 8) * (-(-Co // bn))
     report(f"fwd {Ci}->{Co} k{k} H{Hi} [{bm}x{bn}]", stamps("frx_debug_times_fwd", nb), us)
     if k == 1:
@@ -49,6 +49,6 @@ for (Ci, Co, k, st, Hi) in SH:
         fn = lambda: ops.conv_dgrad_bn(d, dz, wt, dx, pro_y=y, pro_coef=coef, epi_y=ey, epi_scale=esc, epi_shift=esh,
                                        epi_mean=emu, epi_invstd=eis, epi_partial=ep)
         us = timeit(fn)
-        bm, bn = ops._igemm_tile(M, Ci)
+        bm, bn = ops._igemm_tile(d, True)
         nb = ((-(-M // bm) + 7) // 8 * 8) * (-(-Ci // bn))
         report(f"dgrad_bn {Ci}<-{Co} k{k} H{Hi} [{bm}x{bn}]", stamps("frx_debug_times_dgrad_bn", nb), us)

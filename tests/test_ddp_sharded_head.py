@@ -144,7 +144,9 @@ def _worker(rank, world, port, q):
         o = st.step(x[sl], y[sl], 0.1)
         outs.append((o["loss"].item(), o["top1"]))
     assert eng.calls[:8] == ["backbone", "cos", "rows", "rescale", "head_bwd", "upper", "lower", "update"]
-    q.put((rank, eng.params[:eng.n1].clone(), eng._wh().clone(), outs))
+    # numpy arrays travel by value: a torch tensor in an mp queue is a shared-memory handle that dies with this process,
+    # which under load can happen before the parent has mapped it
+    q.put((rank, eng.params[:eng.n1].numpy().copy(), eng._wh().numpy().copy(), outs))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -168,7 +170,7 @@ def test_class_sharded_head_world2_equals_the_unsharded_single_process_step():
     for x, y in _data(12, 3):
         o = st.step(x, y, 0.1)
         ref_out.append((o["loss"].item(), o["top1"]))
-    (_, w1a, wha, oa), (_, w1b, whb, ob) = res
+    (_, w1a, wha, oa), (_, w1b, whb, ob) = [(r, torch.from_numpy(a), torch.from_numpy(b), o) for r, a, b, o in res]
     assert torch.equal(w1a, w1b), "backbone replicas diverged"
     assert (w1a - ref.params[:ref.n1]).abs().max().item() < 1e-9
     assert (torch.cat([wha, whb]) - ref._wh()).abs().max().item() < 1e-9        # shards side by side == the unsharded head

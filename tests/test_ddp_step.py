@@ -111,7 +111,9 @@ def _worker(rank, world, port, q, exchange, bf16):
         sl = slice(rank * n, (rank + 1) * n)
         losses.append(st.step(x[sl], y[sl], 0.05)["loss"].item())
     assert eng.calls[1:6] == ["pre", "forward", "upper", "lower", "update"]
-    q.put((rank, eng.params.clone(), eng.t.clone(), losses))
+    # numpy arrays travel by value: a torch tensor in an mp queue is a shared-memory handle that dies with this process,
+    # which under load can happen before the parent has mapped it
+    q.put((rank, eng.params.numpy().copy(), eng.t.numpy().copy(), losses))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -130,7 +132,7 @@ def test_data_parallel_step_world2_equals_single_process_on_the_concatenated_bat
         p.join(60)
         assert p.exitcode == 0
     ref, ref_losses = _single(16, 3, exchange)
-    (_, p0, t0, l0), (_, p1, t1, l1) = res
+    (_, p0, t0, l0), (_, p1, t1, l1) = [(r, torch.from_numpy(a), torch.from_numpy(b), l) for r, a, b, l in res]
     assert torch.equal(p0, p1) and torch.equal(t0, t1), "replicas diverged"
     tol = 3e-3 if bf16 else 1e-12                    # bf16 buckets round each gradient to 8 bits of mantissa
     assert (p0 - ref.params).abs().max().item() < tol * ref.params.abs().max().item()
