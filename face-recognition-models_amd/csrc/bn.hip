@@ -376,6 +376,14 @@ __global__ __launch_bounds__(256) void k_pool_fwd(int N, int H, int W, int C, co
   }
 }
 
+// x / d for x * d < 2^32 by one multiply-high (m = ceil(2^32 / d)): the pool kernels decompose a flat index per element,
+// and 64-bit divisions by run-time W, H were most of their instructions
+struct FastDiv {
+  unsigned d, m;
+  __device__ __forceinline__ explicit FastDiv(int d_) : d((unsigned)d_), m((unsigned)((0x100000000ull + (unsigned)d_ - 1) / (unsigned)d_)) {}
+  __device__ __forceinline__ unsigned div(unsigned x) const { return d == 1 ? x : __umulhi(x, m); }
+};
+
 // gradient w.r.t. the post-ReLU stem activation: gather from the <=4 windows covering a pixel
 template <typename T>
 __global__ __launch_bounds__(256) void k_pool_bwd(int N, int H, int W, int C, const T* __restrict__ dout,
@@ -386,12 +394,10 @@ __global__ __launch_bounds__(256) void k_pool_bwd(int N, int H, int W, int C, co
   // XCD-contiguous index ranges (block b runs on XCD b % 8): the overlapping 3x3 windows of neighbouring rows are
   // then fetched into ONE L2 instead of up to four (225 -> ~150 MB of HBM traffic for the backward)
   const long chunk = (total + 7) / 8, lo = (long)(blockIdx.x & 7) * chunk, hi = lo + chunk < total ? lo + chunk : total;
+  const FastDiv dG(G), dW(W), dH(H);                 // (total < 2^31 and the divisor bound are checked on the host)
   for (long i = lo + (long)(blockIdx.x >> 3) * 256 + threadIdx.x; i < hi; i += (long)(gridDim.x >> 3) * 256) {
-    const int g = (int)(i % G);
-    long p = i / G;
-    const int w = (int)(p % W); p /= W;
-    const int h = (int)(p % H);
-    const int n = (int)(p / H);
+    const unsigned p0 = dG.div((unsigned)i), p1 = dW.div(p0), p2 = dH.div(p1);
+    const int g = (int)((unsigned)i - p0 * (unsigned)G), w = (int)(p0 - p1 * (unsigned)W), h = (int)(p1 - p2 * (unsigned)H), n = (int)p2;
     float acc[V];
 #pragma unroll
     for (int j = 0; j < V; ++j) acc[j] = 0.f;
@@ -416,6 +422,106 @@ __global__ __launch_bounds__(256) void k_pool_bwd(int N, int H, int W, int C, co
 #pragma unroll
     for (int j = 0; j < V; ++j) r.set(j, acc[j]);
     reinterpret_cast<uint4*>(dpost)[i] = r.raw;
+  }
+}
+
+// Stem backward without the full-resolution gradient in memory: the max-pool gather (above) feeds the BatchNorm/ReLU
+// backward directly.  APPLY = false: dz = gather * (scale*y + shift > 0); per-block partial sums (sum dz, sum dz*xhat)
+// -> partial [gridDim][2][C] (the layout frx_bn_bwd_finalize reads).  APPLY = true: the same dz, then
+// dy = alpha*dz + beta*y + gam -> dy.  Both passes re-gather from the 4x smaller pooled gradient (L2-resident per XCD)
+// instead of writing the [N,H,W,C] gradient once and reading it twice.
+template <typename T, bool APPLY>
+__global__ __launch_bounds__(256) void k_stem_bwd(int N, int H, int W, int C, const T* __restrict__ dout,
+                                                  const uint8_t* __restrict__ argmax, const T* __restrict__ y,
+                                                  const float* __restrict__ scale, const float* __restrict__ shift,
+                                                  const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                  const float* __restrict__ coef, T* __restrict__ dy,
+                                                  float* __restrict__ partial) {
+  constexpr int V = Vec16<T>::N;
+  __shared__ float red[2][256][V + 1];
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1, G = C / V;
+  // One thread = one 2x2 pixel quad (rows 2a, 2a+1; columns 2b, 2b+1) of one channel group: the four windows (a..a+1,
+  // b..b+1) that cover it are loaded ONCE and serve its four pixels (9 of the 16 pixel-window pairs are live), instead
+  // of 2.25 window visits per pixel with lane-divergent trip counts.
+  const int Hq = (H + 1) >> 1, Wq = (W + 1) >> 1;
+  const long total = (long)N * Hq * Wq * G;
+  const long chunk = (total + 7) / 8, lo = (long)(blockIdx.x & 7) * chunk, hi = lo + chunk < total ? lo + chunk : total;
+  const long first = lo + (long)(blockIdx.x >> 3) * 256 + threadIdx.x, step = (long)(gridDim.x >> 3) * 256;
+  // (256 % G == 0, checked on the host: a thread keeps ONE channel group, so its constants stay in registers)
+  const int c = (int)(first % G) * V;
+  float sc[V], sh[V], mu[V], is[V], al[V], be[V], ga[V], s1[V], s2[V];
+  load_consts<V>(scale + c, sc); load_consts<V>(shift + c, sh);
+  if constexpr (APPLY) { load_consts<V>(coef + c, al); load_consts<V>(coef + C + c, be); load_consts<V>(coef + 2 * C + c, ga); }
+  else { load_consts<V>(mean + c, mu); load_consts<V>(invstd + c, is); fill_consts<V>(0.f, s1); fill_consts<V>(0.f, s2); }
+  const FastDiv dG(G), dW(Wq), dH(Hq);               // (the index bound is checked on the host)
+  for (long i = first; i < hi; i += step) {
+    const unsigned p0 = dG.div((unsigned)i), p1 = dW.div(p0), p2 = dH.div(p1);
+    const int g = (int)((unsigned)i - p0 * (unsigned)G), b = (int)(p0 - p1 * (unsigned)Wq), a = (int)(p1 - p2 * (unsigned)Hq), n = (int)p2;
+    // the four windows: index 2*dh + dw  <->  (a + dh, b + dw); absent ones (past the pooled grid) read window (a, b)
+    // again under a code no pixel matches
+    Vec16<T> d[4];
+    uint8_t am[4][V];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int oh = a + (k >> 1), ow = b + (k & 1);
+      const bool ok = oh < Ho && ow < Wo;
+      const long o = ((((long)n * Ho + (ok ? oh : a)) * Wo + (ok ? ow : b)) * G + g);
+      d[k].raw = reinterpret_cast<const uint4*>(dout)[o];
+      if constexpr (V == 8) *reinterpret_cast<uint2*>(am[k]) = *reinterpret_cast<const uint2*>(argmax + o * V);
+      else *reinterpret_cast<uint32_t*>(am[k]) = *reinterpret_cast<const uint32_t*>(argmax + o * V);
+      if (!ok) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) am[k][j] = 255;
+      }
+    }
+    Vec16<T> vy[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int h = 2 * a + (q >> 1), w = 2 * b + (q & 1);
+      const bool ok = h < H && w < W;
+      vy[q].raw = reinterpret_cast<const uint4*>(y)[((((long)n * H + (ok ? h : 2 * a)) * W + (ok ? w : 2 * b)) * G + g)];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int ph = q >> 1, pw = q & 1;                 // pixel (2a + ph, 2b + pw)
+      const int h = 2 * a + ph, w = 2 * b + pw;
+      if (h >= H || w >= W) continue;                    // (odd H / W: the quad hangs over the edge)
+      float acc[V];
+      fill_consts<V>(0.f, acc);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int dh = k >> 1, dw = k & 1;
+        if ((dh && !ph) || (dw && !pw)) continue;        // even rows / columns lie in ONE window row / column
+        const int code = (ph + 1 - 2 * dh) * 3 + (pw + 1 - 2 * dw);      // kh = h - (2*oh - 1), kw likewise
+#pragma unroll
+        for (int j = 0; j < V; ++j) if (am[k][j] == code) acc[j] += d[k].get(j);
+      }
+      Vec16<T> r;
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        const float yy = vy[q].get(j);
+        // (the gathered sum is rounded to T first: what the stand-alone pool backward stored)
+        Vec16<T> t1; t1.set(0, acc[j]);
+        const float dz = fmaf(yy, sc[j], sh[j]) > 0.f ? t1.get(0) : 0.f;
+        if constexpr (APPLY) r.set(j, fmaf(al[j], dz, fmaf(be[j], yy, ga[j])));
+        else { s1[j] += dz; s2[j] += dz * (yy - mu[j]) * is[j]; }
+      }
+      if constexpr (APPLY) reinterpret_cast<uint4*>(dy)[(((long)n * H + h) * W + w) * G + g] = r.raw;
+    }
+  }
+  if constexpr (!APPLY) {
+#pragma unroll
+    for (int j = 0; j < V; ++j) { red[0][threadIdx.x][j] = s1[j]; red[1][threadIdx.x][j] = s2[j]; }
+    __syncthreads();
+    if (threadIdx.x < G) {      // thread t sums the threads t, t + G, ... (all on t's channel group)
+#pragma unroll
+      for (int j = 0; j < V; ++j) {
+        float a = 0.f, b = 0.f;
+        for (int k = threadIdx.x; k < 256; k += G) { a += red[0][k][j]; b += red[1][k][j]; }
+        partial[((long)blockIdx.x * 2 + 0) * C + c + j] = a;
+        partial[((long)blockIdx.x * 2 + 1) * C + c + j] = b;
+      }
+    }
   }
 }
 
@@ -458,6 +564,12 @@ static inline int pool_grid(long work_items) {       // multiple of 8: the pool 
   if (b > 256 * 16) b = 256 * 16;
   b = (b + 7) / 8 * 8;
   return (int)b;
+}
+
+// FastDiv's exactness bound for the flat (n, h, w, group) index of the pool kernels
+static inline bool pool_index_ok(long N, long H, long W, long G) {
+  const long total = N * H * W * G, dmax = W > H ? (W > G ? W : G) : (H > G ? H : G);
+  return total > 0 && total * dmax < 0x100000000l;
 }
 
 static inline int ew_grid(long work_items) {
@@ -617,6 +729,7 @@ extern "C" int frx_stem_pool_bwd(int device, frx_stream_t stream, int dtype, int
                                  const void* dout, const uint8_t* argmax, void* dpost) {
   FRX_DT_CHECK(dtype);
   FRX_CHECK_ARG(dout && argmax && dpost && N > 0 && H > 1 && W > 1 && C > 0 && C % FRX_VEC(dtype) == 0, "stem_pool_bwd: bad args");
+  FRX_CHECK_ARG(pool_index_ok(N, H, W, C / FRX_VEC(dtype)), "stem_pool_bwd: N*H*W*C/%d must stay below 2^31 / max(W, H, C)", FRX_VEC(dtype));
   FRX_ENTER(device);
   const long total = (long)N * H * W * C / FRX_VEC(dtype);
   if (dtype == FRX_BF16)
@@ -627,6 +740,46 @@ extern "C" int frx_stem_pool_bwd(int device, frx_stream_t stream, int dtype, int
                        (const float*)dout, argmax, (float*)dpost);
   FRX_LAUNCH_CHECK();
   return FRX_OK;
+}
+
+// Fused stem backward (pool gather -> ReLU mask -> BatchNorm backward), two passes around frx_bn_bwd_finalize:
+//   frx_stem_bwd_reduce -> partial [frx_stem_bwd_partial_rows()][2][C];  frx_stem_bwd_apply -> dy
+extern "C" int frx_stem_bwd_partial_rows(void) { return 1024; }
+
+static int stem_bwd_impl(int device, frx_stream_t stream, int dtype, int N, int H, int W, int C, const void* dout,
+                         const uint8_t* argmax, const void* y, const float* scale, const float* shift, const float* mean,
+                         const float* invstd, const float* coef, void* dy, float* partial) {
+  FRX_DT_CHECK(dtype);
+  FRX_CHECK_ARG(dout && argmax && y && scale && shift && N > 0 && H > 1 && W > 1 && C > 0 && C % FRX_VEC(dtype) == 0, "stem_bwd: bad args");
+  const int G = C / FRX_VEC(dtype);
+  FRX_CHECK_ARG(G <= 256 && 256 % G == 0, "stem_bwd: C=%d must give a power-of-two number (<= 256) of 16-byte groups", C);
+  FRX_CHECK_ARG(pool_index_ok(N, H, W, G), "stem_bwd: N*H*W*C/%d must stay below 2^31 / max(W, H, C)", FRX_VEC(dtype));
+  FRX_ENTER(device);
+  const dim3 grid(dy ? pool_grid((long)N * ((H + 1) / 2) * ((W + 1) / 2) * G) : frx_stem_bwd_partial_rows()), blk(256);      // (both multiples of 8)
+  const hipStream_t st = (hipStream_t)stream;
+  if (dy) {
+    if (dtype == FRX_BF16) hipLaunchKernelGGL((k_stem_bwd<bf16_t, true>), grid, blk, 0, st, N, H, W, C, (const bf16_t*)dout, argmax, (const bf16_t*)y, scale, shift, mean, invstd, coef, (bf16_t*)dy, partial);
+    else hipLaunchKernelGGL((k_stem_bwd<float, true>), grid, blk, 0, st, N, H, W, C, (const float*)dout, argmax, (const float*)y, scale, shift, mean, invstd, coef, (float*)dy, partial);
+  } else {
+    if (dtype == FRX_BF16) hipLaunchKernelGGL((k_stem_bwd<bf16_t, false>), grid, blk, 0, st, N, H, W, C, (const bf16_t*)dout, argmax, (const bf16_t*)y, scale, shift, mean, invstd, coef, (bf16_t*)dy, partial);
+    else hipLaunchKernelGGL((k_stem_bwd<float, false>), grid, blk, 0, st, N, H, W, C, (const float*)dout, argmax, (const float*)y, scale, shift, mean, invstd, coef, (float*)dy, partial);
+  }
+  FRX_LAUNCH_CHECK();
+  return FRX_OK;
+}
+
+extern "C" int frx_stem_bwd_reduce(int device, frx_stream_t stream, int dtype, int N, int H, int W, int C, const void* dout,
+                                   const uint8_t* argmax, const void* y, const float* scale, const float* shift,
+                                   const float* mean, const float* invstd, float* partial) {
+  FRX_CHECK_ARG(mean && invstd && partial, "stem_bwd_reduce: NULL pointer");
+  return stem_bwd_impl(device, stream, dtype, N, H, W, C, dout, argmax, y, scale, shift, mean, invstd, nullptr, nullptr, partial);
+}
+
+extern "C" int frx_stem_bwd_apply(int device, frx_stream_t stream, int dtype, int N, int H, int W, int C, const void* dout,
+                                  const uint8_t* argmax, const void* y, const float* scale, const float* shift,
+                                  const float* coef, void* dy) {
+  FRX_CHECK_ARG(coef && dy, "stem_bwd_apply: NULL pointer");
+  return stem_bwd_impl(device, stream, dtype, N, H, W, C, dout, argmax, y, scale, shift, nullptr, nullptr, coef, dy, nullptr);
 }
 
 extern "C" int frx_avgpool_fwd(int device, frx_stream_t stream, int dtype, int N, int HW, int C, const void* x, void* out) {

@@ -88,6 +88,9 @@ _SIGS = {
     "frx_bn_bwd_apply": (C.c_int, [C.c_int, _P, C.c_int, C.c_int64, C.c_int, _P, _P, _P, _P, _P, C.c_int,
                                    _P, _P, _P, _P]),
     "frx_stem_pool_fwd": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P]),
+    "frx_stem_bwd_partial_rows": (C.c_int, []),
+    "frx_stem_bwd_reduce": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
+    "frx_stem_bwd_apply": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P]),
     "frx_stem_pool_bwd": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "frx_avgpool_fwd": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),
     "frx_avgpool_bwd": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P]),

@@ -185,12 +185,13 @@ class ResNet50Engine:
         max_act = max(c.y.numel() for c in self.convs)
         self.scratch = [torch.zeros(max_act, dtype=self.tdt, device=dev) for _ in range(5)]
         max_bp = max(ops.bn_bwd_partial_rows(c.y.numel() // c.Co, c.Co) * c.Co for c in self.convs)
-        max_bp = max([max_bp] + [ops.conv_dgrad_stat_rows(c.desc) * c.Ci for c in self.convs if not c.stem])
+        max_bp = max([max_bp, ops.stem_bwd_partial_rows() * 64] + [ops.conv_dgrad_stat_rows(c.desc) * c.Ci for c in self.convs if not c.stem])
         self.bwd_partial = torch.zeros(2 * max_bp, device=dev)
         self.coef = torch.zeros(3 * 2048, device=dev)
         self.g_pool = torch.zeros_like(self.pool_out)        # gradient w.r.t. the max-pool output
         self.dy_stem = torch.zeros_like(self.stem.y)
         self.grouped_wgrad = os.environ.get("FRX_WGRAD_GROUPED", "1") != "0"
+        self.fused_stem_bwd = os.environ.get("FRX_FUSED_STEM_BWD", "1") != "0"
         self.mask_bits = os.environ.get("FRX_MASK_BITS", "1") != "0"
         self._wg_groups = None                               # planned at the end of __init__ (needs every buffer)
         self.dfeat_t = torch.zeros(N, FEATURE_DIM, dtype=self.tdt, device=dev)
@@ -512,9 +513,18 @@ class ResNet50Engine:
         N, dt = self.N, self.dtype
         S = self.scratch
         s = self.stem
-        dpost = self._like(S[2], s.y)
-        ops.stem_pool_bwd(dt, N, s.Ho, s.Ho, 64, self.g_pool, self.pool_arg, dpost)
-        self._bn_backward(s, dpost, self.dy_stem, relu=True)
+        if self.fused_stem_bwd:
+            # two passes that re-gather from the pooled gradient instead of storing the 56x56 gradient and reading it twice
+            sc, sh = self._bn(self.bn_scale, s), self._bn(self.bn_shift, s)
+            mean, invstd = self._bn(self.bn_mean, s), self._bn(self.bn_invstd, s)
+            ops.stem_bwd_reduce(dt, N, s.Ho, s.Ho, 64, self.g_pool, self.pool_arg, s.y, sc, sh, mean, invstd, self.bwd_partial)
+            ops.bn_bwd_finalize(self.bwd_partial, ops.stem_bwd_partial_rows(), 64, s.y.numel() // 64, self.gamma(s), mean, invstd,
+                                self.gamma(s, self.grads), self.beta(s, self.grads), self.coef)
+            ops.stem_bwd_apply(dt, N, s.Ho, s.Ho, 64, self.g_pool, self.pool_arg, s.y, sc, sh, self.coef, self.dy_stem)
+        else:
+            dpost = self._like(S[2], s.y)
+            ops.stem_pool_bwd(dt, N, s.Ho, s.Ho, 64, self.g_pool, self.pool_arg, dpost)
+            self._bn_backward(s, dpost, self.dy_stem, relu=True)
         self._wgrad(s, self.xin, self.dy_stem)     # (padding tap / channel slots are not written)
 
     # ------------------------------------------------------------------ weight gradients

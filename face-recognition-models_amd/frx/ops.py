@@ -446,6 +446,22 @@ def stem_pool_fwd(dtype, N, H, W, Cc, y, scale, shift, out, argmax):
                                        _p(argmax)), "frx_stem_pool_fwd")
 
 
+def stem_bwd_partial_rows():
+    return _lib.lib().frx_stem_bwd_partial_rows()
+
+
+def stem_bwd_reduce(dtype, N, H, W, Cc, dout, argmax, y, scale, shift, mean, invstd, partial):
+    """pool gather -> ReLU mask -> (sum dz, sum dz*xhat) partials, without the full-resolution gradient in memory"""
+    check(_lib.lib().frx_stem_bwd_reduce(_dev(dout), _stream(dout), dtype, N, H, W, Cc, _p(dout), _p(argmax), _p(y), _p(scale),
+                                         _p(shift), _p(mean), _p(invstd), _p(partial)), "frx_stem_bwd_reduce")
+
+
+def stem_bwd_apply(dtype, N, H, W, Cc, dout, argmax, y, scale, shift, coef, dy):
+    check(_lib.lib().frx_stem_bwd_apply(_dev(dout), _stream(dout), dtype, N, H, W, Cc, _p(dout), _p(argmax), _p(y), _p(scale),
+                                        _p(shift), _p(coef), _p(dy)), "frx_stem_bwd_apply")
+    return dy
+
+
 def stem_pool_bwd(dtype, N, H, W, Cc, dout, argmax, dpost):
     check(_lib.lib().frx_stem_pool_bwd(_dev(dout), _stream(dout), dtype, N, H, W, Cc, _p(dout), _p(argmax), _p(dpost)),
           "frx_stem_pool_bwd")

@@ -302,6 +302,18 @@ int frx_stem_pool_fwd(int device, frx_stream_t stream, int dtype, int N, int H, 
                       const float* scale, const float* shift, void* out, uint8_t* argmax);
 int frx_stem_pool_bwd(int device, frx_stream_t stream, int dtype, int N, int H, int W, int C, const void* dout,
                       const uint8_t* argmax, void* dpost);
+/* The stem's backward in two passes that never store the full-resolution gradient: the max-pool gather of
+ * frx_stem_pool_bwd feeds the ReLU mask (scale*y + shift > 0) and the BatchNorm backward directly.
+ *   frx_stem_bwd_reduce -> partial [frx_stem_bwd_partial_rows()][2][C]  (then frx_bn_bwd_finalize -> coef)
+ *   frx_stem_bwd_apply  -> dy = alpha*dz + beta*y + gam                  (the stem conv's output gradient)
+ * Same values as frx_stem_pool_bwd + frx_bn_bwd_reduce(relu) + frx_bn_bwd_apply(relu). */
+int frx_stem_bwd_partial_rows(void);
+int frx_stem_bwd_reduce(int device, frx_stream_t stream, int dtype, int N, int H, int W, int C, const void* dout,
+                        const uint8_t* argmax, const void* y, const float* scale, const float* shift, const float* mean,
+                        const float* invstd, float* partial);
+int frx_stem_bwd_apply(int device, frx_stream_t stream, int dtype, int N, int H, int W, int C, const void* dout,
+                       const uint8_t* argmax, const void* y, const float* scale, const float* shift, const float* coef,
+                       void* dy);
 int frx_avgpool_fwd(int device, frx_stream_t stream, int dtype, int N, int HW, int C, const void* x, void* out);
 int frx_avgpool_bwd(int device, frx_stream_t stream, int dtype, int N, int HW, int C, const void* dpool, void* dx);
 

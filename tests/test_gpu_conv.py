@@ -335,3 +335,61 @@ def test_block_merge_mask_bits(dtype):
     assert torch.equal(out, ref)
     want = ((ref.float() > 0).view(-1, V).to(torch.int32) << torch.arange(V, device=DEV, dtype=torch.int32)).sum(1).to(torch.uint8)
     assert torch.equal(mask, want)
+
+
+@pytest.mark.parametrize("dtype", [0, 1], ids=["f32", "bf16"])
+@pytest.mark.parametrize("geom", [(4, 56, 64), (3, 14, 64), (2, 9, 32)], ids=["56", "14", "odd9"])
+def test_fused_stem_backward(dtype, geom):
+    """frx_stem_bwd_reduce / frx_stem_bwd_apply (pool gather feeding the ReLU mask and the BatchNorm backward) == the
+    stand-alone frx_stem_pool_bwd + frx_bn_bwd_reduce(relu) + frx_bn_bwd_apply(relu); in fp32 also == ATen's max_pool2d /
+    ReLU backward followed by the closed-form BatchNorm backward."""
+    from frx import ops
+    N, H, Cc = geom
+    Ho = (H + 2 - 3) // 2 + 1
+    tdt = ops.TORCH_DT[dtype]
+    g = torch.Generator().manual_seed(H)
+    y = torch.randn(N, H, H, Cc, generator=g).to(tdt).to(DEV)
+    scale = (torch.rand(Cc, generator=g) + 0.5).to(DEV)
+    shift = (torch.randn(Cc, generator=g) * 0.3).to(DEV)
+    mean = (torch.randn(Cc, generator=g) * 0.2).to(DEV)
+    invstd = (torch.rand(Cc, generator=g) + 0.7).to(DEV)
+    gamma = (torch.rand(Cc, generator=g) + 0.5).to(DEV)
+    dout = torch.randn(N, Ho, Ho, Cc, generator=g).to(tdt).to(DEV)
+    pooled = torch.empty(N, Ho, Ho, Cc, dtype=tdt, device=DEV)
+    arg = torch.empty(N, Ho, Ho, Cc, dtype=torch.uint8, device=DEV)
+    ops.stem_pool_fwd(dtype, N, H, H, Cc, y, scale, shift, pooled, arg)
+    rows = N * H * H
+    # stand-alone chain
+    dpost = torch.empty_like(y)
+    ops.stem_pool_bwd(dtype, N, H, H, Cc, dout, arg, dpost)
+    nblk = ops.bn_bwd_partial_rows(rows, Cc)
+    part = torch.zeros(max(nblk, ops.stem_bwd_partial_rows()) * 2 * Cc, device=DEV)
+    ops.bn_bwd_reduce(dtype, rows, Cc, dpost, y, mean, invstd, part, scale=scale, shift=shift, relu=True)
+    dga, dbe, coef = torch.zeros(Cc, device=DEV), torch.zeros(Cc, device=DEV), torch.zeros(3 * Cc, device=DEV)
+    ops.bn_bwd_finalize(part, nblk, Cc, rows, gamma, mean, invstd, dga, dbe, coef)
+    dy_ref = torch.empty_like(y)
+    ops.bn_bwd_apply(dtype, rows, Cc, dpost, y, mean, invstd, coef, dy_ref, scale=scale, shift=shift, relu=True)
+    # fused chain
+    part2 = torch.zeros_like(part)
+    ops.stem_bwd_reduce(dtype, N, H, H, Cc, dout, arg, y, scale, shift, mean, invstd, part2)
+    dga2, dbe2, coef2 = torch.zeros(Cc, device=DEV), torch.zeros(Cc, device=DEV), torch.zeros(3 * Cc, device=DEV)
+    ops.bn_bwd_finalize(part2, ops.stem_bwd_partial_rows(), Cc, rows, gamma, mean, invstd, dga2, dbe2, coef2)
+    dy = torch.empty_like(y)
+    ops.stem_bwd_apply(dtype, N, H, H, Cc, dout, arg, y, scale, shift, coef2, dy)
+    torch.cuda.synchronize()
+    for a, b, what in ((dga2, dga, "dgamma"), (dbe2, dbe, "dbeta"), (coef2, coef, "coef")):
+        assert (a - b).abs().max().item() <= 1e-5 * b.abs().max().item() + 1e-6, what
+    # same dz, coefficients equal to ~1e-6: dy agrees to an ulp of the storage type
+    _close(dy, dy_ref.float().cpu(), dtype, "fused dy vs stand-alone")
+    assert (dy.float() - dy_ref.float()).abs().max().item() <= (2e-6 if dtype == ops.F32 else 2 ** -7) * dy_ref.float().abs().max().item()
+    if dtype == ops.F32:
+        yc = y.cpu().permute(0, 3, 1, 2).contiguous().requires_grad_(True)
+        sc, sh = scale.cpu().view(1, -1, 1, 1), shift.cpu().view(1, -1, 1, 1)
+        p = F.max_pool2d(F.relu(yc * sc + sh), 3, 2, 1)
+        (dpre,) = torch.autograd.grad(p, yc, dout.cpu().permute(0, 3, 1, 2))          # = dz * scale (chain through the affine)
+        dz = dpre / sc
+        xhat = (yc.detach() - mean.cpu().view(1, -1, 1, 1)) * invstd.cpu().view(1, -1, 1, 1)
+        m1, m2 = dz.mean((0, 2, 3), keepdim=True), (dz * xhat).mean((0, 2, 3), keepdim=True)
+        want = (gamma.cpu() * invstd.cpu()).view(1, -1, 1, 1) * (dz - m1 - xhat * m2)
+        _close(dy, want.permute(0, 2, 3, 1), dtype, "fused dy vs ATen")
+        assert (dbe2.cpu() - dz.sum((0, 2, 3))).abs().max().item() < 1e-3 and (dga2.cpu() - (dz * xhat).sum((0, 2, 3))).abs().max().item() < 1e-3
