@@ -676,7 +676,8 @@ __global__ __launch_bounds__(256) void k_shard_finish(HeadConst h, int N, const 
 __global__ __launch_bounds__(256) void k_head_finalize(const float* __restrict__ rowloss,
                                                        const int32_t* __restrict__ rowrank, int N,
                                                        float* __restrict__ loss, int32_t* __restrict__ topk,
-                                                       float* __restrict__ lse_ws_copy_src_unused) {
+                                                       const float* __restrict__ lse_ws, float* __restrict__ lse_out,
+                                                       const float* __restrict__ norms_ws, float* __restrict__ norms_out) {
   __shared__ float sh[4];
   __shared__ int s1[4], s5[4];
   float a = 0.f;
@@ -685,6 +686,9 @@ __global__ __launch_bounds__(256) void k_head_finalize(const float* __restrict__
     a += rowloss[n];
     c1 += rowrank[n] < 1;
     c5 += rowrank[n] < 5;
+    // the caller's copies of the per-row outputs ride along (each was a dependent launch of its own for N floats)
+    if (lse_out) lse_out[n] = lse_ws[n];
+    if (norms_out) norms_out[n] = norms_ws[n];
   }
   a = block_sum256(a, sh);
   c1 = wave_sum_i(c1);
@@ -708,10 +712,14 @@ __global__ __launch_bounds__(256) void k_head_grad(HeadConst h, const float* __r
                                                    const float* __restrict__ lse,
                                                    const float* __restrict__ gout, float inv_n,
                                                    const float* __restrict__ dlogits,
-                                                   float* __restrict__ gbuf, float* __restrict__ dn) {
+                                                   float* __restrict__ gbuf, float* __restrict__ dn,
+                                                   float* __restrict__ zero_rows, int zero_len) {
   __shared__ float sh[4];
   if (KIND == FRX_SPHERE && (h.flags & 4)) h.lamb = *state_t;
   const int n = blockIdx.x;
+  // row n of the split-K accumulator of the dX GEMM that follows is cleared here (it was a launch of its own; a kernel,
+  // not a memset node: see head_bwd_impl)
+  for (int j = threadIdx.x; j < zero_len; j += 256) zero_rows[(long)n * zero_len + j] = 0.f;
   bool bad_label, owned;
   const int y = shard_label(labels[n], h, C, owned, bad_label);
   const float* crow = cbuf + (long)n * Cpad;
@@ -836,12 +844,6 @@ __global__ __launch_bounds__(256) void k_norm_bwd_cols(const float* __restrict__
       if (d < D) out[(long)d * C + c] = (vd[u] - va[u] * iv * dot) * iv + vo[u];
     }
   }
-}
-
-// zero n4 float4s (D % 16 == 0 keeps every head buffer a multiple of 16 bytes)
-__global__ __launch_bounds__(256) void k_zero_f32(float* __restrict__ p, long n4) {
-  const long i = (long)blockIdx.x * 256 + threadIdx.x;
-  if (i < n4) reinterpret_cast<float4*>(p)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
 }
 
 __global__ __launch_bounds__(256) void k_copy_f32(const float* __restrict__ x, float* __restrict__ y, long n) {
@@ -1052,13 +1054,11 @@ extern "C" int frx_head_fwd_loss(int device, frx_stream_t stream, const frx_head
   FRX_KIND_SWITCH(d->kind, FRX_ROWS)
 #undef FRX_ROWS
   FRX_LAUNCH_CHECK();
+  // (lse / norms are copied by the same kernel: no memcpy nodes in a captured step -- see head_bwd_impl -- and no launches
+  // of their own)
   hipLaunchKernelGGL(k_head_finalize, dim3(1), dim3(256), 0, st, (const float*)W.rowloss,
-                     (const int32_t*)W.rowrank, d->N, loss, topk, (float*)nullptr);
-  FRX_LAUNCH_CHECK();
-  // (kernels rather than hipMemcpyAsync: no memcpy / memset nodes in a captured step, see head_bwd_impl)
-  if (lse) hipLaunchKernelGGL(k_copy_f32, dim3(cdiv(d->N, 256)), dim3(256), 0, st, (const float*)W.lse, lse, (long)d->N);
-  if (norms) hipLaunchKernelGGL(k_copy_f32, dim3(cdiv(d->N, 256)), dim3(256), 0, st,
-                                (const float*)(d->kind == FRX_MAG ? W.xn : W.xnorm), norms, (long)d->N);
+                     (const int32_t*)W.rowrank, d->N, loss, topk, (const float*)W.lse, lse,
+                     (const float*)(d->kind == FRX_MAG ? W.xn : W.xnorm), norms);
   FRX_LAUNCH_CHECK();
   return FRX_OK;
 }
@@ -1150,9 +1150,7 @@ extern "C" int frx_head_shard_finish(int device, frx_stream_t stream, const frx_
   FRX_KIND_SWITCH(d->kind, FRX_FIN)
 #undef FRX_FIN
   hipLaunchKernelGGL(k_head_finalize, dim3(1), dim3(256), 0, st, (const float*)W.rowloss, (const int32_t*)W.rowrank, d->N, loss,
-                     topk, (float*)nullptr);
-  if (lse) hipLaunchKernelGGL(k_copy_f32, dim3(cdiv(d->N, 256)), dim3(256), 0, st, (const float*)W.lse, lse, (long)d->N);
-  if (norms) hipLaunchKernelGGL(k_copy_f32, dim3(cdiv(d->N, 256)), dim3(256), 0, st, (const float*)W.xnorm, norms, (long)d->N);
+                     topk, (const float*)W.lse, lse, (const float*)W.xnorm, norms);
   FRX_LAUNCH_CHECK();
   return FRX_OK;
 }
@@ -1208,7 +1206,7 @@ static int head_bwd_impl(int device, frx_stream_t stream, const frx_head_desc* d
 #define FRX_GRAD(K)                                                                                  \
   hipLaunchKernelGGL(k_head_grad<K>, dim3(d->N), dim3(256), 0, st, h, (const float*)W.cbuf, d->C,    \
                      W.Cpad, labels, (const float*)W.xnorm, (const float*)W.ty, state_t, rowp,       \
-                     (const float*)W.lse, gout, inv_n, dlogits, W.gbuf, W.dn)
+                     (const float*)W.lse, gout, inv_n, dlogits, W.gbuf, W.dn, W.dxh, d->D)
   FRX_KIND_SWITCH(d->kind, FRX_GRAD)
 #undef FRX_GRAD
   FRX_LAUNCH_CHECK();
@@ -1221,10 +1219,9 @@ static int head_bwd_impl(int device, frx_stream_t stream, const frx_head_desc* d
   }
   // dX^ [N,D] = dC [N,C] . W^   (K = C: split so the grid fills the chip)
   {
-    // (a kernel, not hipMemsetAsync: inside a replayed hipGraph the memset NODE intermittently filled this buffer with
-    // a stale 32-bit pattern instead of 0 -- seen as dfeat ~1e8..1e34 on a fraction of the runs, graph mode only)
-    hipLaunchKernelGGL(k_zero_f32, dim3(cdiv((long)d->N * d->D / 4, 256)), dim3(256), 0, st, W.dxh, (long)d->N * d->D / 4);
-    FRX_LAUNCH_CHECK();
+    // (W.dxh was cleared by k_head_grad, one row per block -- a kernel, not hipMemsetAsync: inside a replayed hipGraph the
+    // memset NODE intermittently filled this buffer with a stale 32-bit pattern instead of 0 -- seen as dfeat ~1e8..1e34
+    // on a fraction of the runs, graph mode only)
     GemmArgs g{};
     g.A = W.gbuf; g.lda = W.Cpad; g.a_mcontig = 0; g.a_kscale = W.winv;
     g.B = w; g.M = d->N; g.N = d->D; g.K = d->C;
