@@ -7,7 +7,7 @@ import torch
 from frx import ops
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 DEV = "cuda:0"
-VARIANTS = ["128x128x8x64", "128x128x9x64", "128x128x17x64", "128x128x16x64"]
+VARIANTS = ["128x128x8x64", "128x64x4x64", "64x64x4x64", "64x128x4x128"]        # the instantiations FRX_IGEMM_LAUNCH knows
 # (Ci, Co, k, stride, Hi)
 SHAPES = [(64, 64, 3, 1, 28), (64, 256, 1, 1, 28), (256, 64, 1, 1, 28), (128, 128, 3, 1, 14), (128, 512, 1, 1, 14), (512, 128, 1, 1, 14),
           (256, 256, 3, 1, 7), (256, 1024, 1, 1, 7), (1024, 256, 1, 1, 7), (512, 512, 3, 1, 4), (512, 2048, 1, 1, 4), (2048, 512, 1, 1, 4),
