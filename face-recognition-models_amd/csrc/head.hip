@@ -84,8 +84,11 @@ __device__ __forceinline__ void gemm_store_tile(float (*S)[GLD], const float v[4
 
 template <bool AMC, bool BNC>
 __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
-  __shared__ __attribute__((aligned(16))) float As[GBK][GLD];
-  __shared__ __attribute__((aligned(16))) float Bs[GBK][GLD];
+  // two LDS stages: the global loads of K-step k+1 are issued before the MFMAs of step k and stored to the other stage
+  // after them -- one barrier per step, the loads' latency under the 8 MFMAs (the single-stage load -> barrier -> store ->
+  // barrier -> MFMA loop left it exposed: 48-75 TFLOP/s, now see DESIGN.md section 8)
+  __shared__ __attribute__((aligned(16))) float As[2][GBK][GLD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][GBK][GLD];
   const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
   const int kbeg = blockIdx.z * g.ksplit_len;
   const int kend = min(g.K, kbeg + g.ksplit_len);
@@ -95,21 +98,32 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
+  float va[4], vb[4];
+  int ax, ak, bx, bk;
+  gemm_load_tile<AMC>(g.A, g.lda, m0, g.M, kbeg, kend, g.a_kscale, va, ax, ak);
+  gemm_load_tile<BNC>(g.B, g.ldb, n0, g.N, kbeg, kend, nullptr, vb, bx, bk);
+  gemm_store_tile<AMC>(As[0], va, ax, ak);
+  gemm_store_tile<BNC>(Bs[0], vb, bx, bk);
+  __syncthreads();
+  int buf = 0;
   for (int k0 = kbeg; k0 < kend; k0 += GBK) {
-    float va[4], vb[4];
-    int ax, ak, bx, bk;
-    gemm_load_tile<AMC>(g.A, g.lda, m0, g.M, k0, kend, g.a_kscale, va, ax, ak);
-    gemm_load_tile<BNC>(g.B, g.ldb, n0, g.N, k0, kend, nullptr, vb, bx, bk);
-    __syncthreads();
-    gemm_store_tile<AMC>(As, va, ax, ak);
-    gemm_store_tile<BNC>(Bs, vb, bx, bk);
-    __syncthreads();
+    const bool more = k0 + GBK < kend;
+    if (more) {
+      gemm_load_tile<AMC>(g.A, g.lda, m0, g.M, k0 + GBK, kend, g.a_kscale, va, ax, ak);
+      gemm_load_tile<BNC>(g.B, g.ldb, n0, g.N, k0 + GBK, kend, nullptr, vb, bx, bk);
+    }
 #pragma unroll
     for (int kk = 0; kk < GBK / 2; ++kk) {
-      const float a = As[2 * kk + lh][wm * 32 + li];
-      const float b = Bs[2 * kk + lh][wn * 32 + li];
+      const float a = As[buf][2 * kk + lh][wm * 32 + li];
+      const float b = Bs[buf][2 * kk + lh][wn * 32 + li];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
+    if (more) {
+      gemm_store_tile<AMC>(As[buf ^ 1], va, ax, ak);
+      gemm_store_tile<BNC>(Bs[buf ^ 1], vb, bx, bk);
+    }
+    __syncthreads();
+    buf ^= 1;
   }
   // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   const int n = n0 + wn * 32 + li;
@@ -589,41 +603,53 @@ __global__ __launch_bounds__(256) void k_head_rows(HeadConst h, const float* __r
   float zy, dummy, u;
   head_z<KIND>(cy, true, h, r, zy, dummy, u);
 
-  // four consecutive classes per thread and trip (16-byte loads; rows are Cpad-strided, Cpad % 64 == 0): a quarter
-  // of the dependent round trips of the one-float walk, which at C = 85 000 was the whole cost of this kernel
+  // four consecutive classes per thread and trip (16-byte loads; rows are Cpad-strided, Cpad % 64 == 0), HU trips' loads
+  // issued before the first use: one block walks a whole row, so its bytes in flight are what bounds it (at C = 85 000
+  // the one-load-per-trip form ran at 3 GB/s per block: 113 us for 128 rows)
+  constexpr int HU = 4;
   float zmax = -INFINITY;
   int rank = 0;
-  for (int j0 = threadIdx.x * 4; j0 < C; j0 += 1024) {
-    const float4 c4 = *reinterpret_cast<const float4*>(crow + j0);
-    const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
+  for (int j0 = threadIdx.x * 4; j0 < C; j0 += 1024 * HU) {
+    float4 c4[HU];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int j = j0 + e;
-      if (j < C) {
-        const float cc = head_clamp<KIND>(cv[e]);
-        float z, d;
-        head_z<KIND>(cc, j == y, h, r, z, d, u);
-        const float cs = head_cos_s<KIND>(cc, h, r);
-        zmax = fmaxf(zmax, z);
-        rank += (cs > cos_s_y) ? 1 : 0;
-        if (cos_s_out) cos_s_out[(long)n * C + j] = cs;
-        if (logits_out) logits_out[(long)n * C + j] = z;
+    for (int t = 0; t < HU; ++t) c4[t] = *reinterpret_cast<const float4*>(crow + (j0 + 1024 * t < C ? j0 + 1024 * t : j0));
+#pragma unroll
+    for (int t = 0; t < HU; ++t) {
+      const float cv[4] = {c4[t].x, c4[t].y, c4[t].z, c4[t].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int j = j0 + 1024 * t + e;
+        if (j < C) {
+          const float cc = head_clamp<KIND>(cv[e]);
+          float z, d;
+          head_z<KIND>(cc, j == y, h, r, z, d, u);
+          const float cs = head_cos_s<KIND>(cc, h, r);
+          zmax = fmaxf(zmax, z);
+          rank += (cs > cos_s_y) ? 1 : 0;
+          if (cos_s_out) cos_s_out[(long)n * C + j] = cs;
+          if (logits_out) logits_out[(long)n * C + j] = z;
+        }
       }
     }
   }
   zmax = block_max256(zmax, sh);
   float se = 0.f;
-  for (int j0 = threadIdx.x * 4; j0 < C; j0 += 1024) {
-    const float4 c4 = *reinterpret_cast<const float4*>(crow + j0);
-    const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
+  for (int j0 = threadIdx.x * 4; j0 < C; j0 += 1024 * HU) {
+    float4 c4[HU];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int j = j0 + e;
-      if (j < C) {
-        const float cc = head_clamp<KIND>(cv[e]);
-        float z, d;
-        head_z<KIND>(cc, j == y, h, r, z, d, u);
-        se += expf(z - zmax);
+    for (int t = 0; t < HU; ++t) c4[t] = *reinterpret_cast<const float4*>(crow + (j0 + 1024 * t < C ? j0 + 1024 * t : j0));
+#pragma unroll
+    for (int t = 0; t < HU; ++t) {
+      const float cv[4] = {c4[t].x, c4[t].y, c4[t].z, c4[t].w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int j = j0 + 1024 * t + e;
+        if (j < C) {
+          const float cc = head_clamp<KIND>(cv[e]);
+          float z, d;
+          head_z<KIND>(cc, j == y, h, r, z, d, u);
+          se += expf(z - zmax);
+        }
       }
     }
   }
@@ -728,28 +754,36 @@ __global__ __launch_bounds__(256) void k_head_grad(HeadConst h, const float* __r
   const float gs = (gout ? *gout : 1.f) * inv_n;
   const float l = lse[n];
   float dnorm = 0.f;
-  for (int j0 = threadIdx.x * 4; j0 < Cpad; j0 += 1024) {       // 16-byte loads / stores, as in k_head_rows
-    const float4 c4 = *reinterpret_cast<const float4*>(crow + j0);
-    const float cv[4] = {c4.x, c4.y, c4.z, c4.w};
-    float ov[4];
+  constexpr int HU = 4;                                            // 16-byte loads / stores, HU trips in flight, as in k_head_rows
+  for (int j0 = threadIdx.x * 4; j0 < Cpad; j0 += 1024 * HU) {
+    float4 c4[HU];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const int j = j0 + e;
-      float out = 0.f;
-      if (j < C) {
-        const float craw = cv[e];
-        const float cc = head_clamp<KIND>(craw);
-        float z, d, u;
-        head_z<KIND>(cc, j == y, h, r, z, d, u);
-        // upstream gradient: mean-CE in closed form, or an arbitrary dL/dlogits supplied by autograd
-        const float g = dlogits ? dlogits[(long)n * C + j] : (expf(z - l) - (j == y ? 1.f : 0.f)) * gs;
-        out = head_pass<KIND>(craw) ? g * d : 0.f;
-        if (KIND == FRX_SPHERE) dnorm += g * u;
-        if (KIND == FRX_MAG && j == y) dnorm += g * u * r.aux;      // through the adaptive margin (criterion.py:1264)
+    for (int t = 0; t < HU; ++t) c4[t] = *reinterpret_cast<const float4*>(crow + (j0 + 1024 * t < Cpad ? j0 + 1024 * t : j0));
+#pragma unroll
+    for (int t = 0; t < HU; ++t) {
+      const int jt = j0 + 1024 * t;
+      if (jt >= Cpad) break;
+      const float cv[4] = {c4[t].x, c4[t].y, c4[t].z, c4[t].w};
+      float ov[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int j = jt + e;
+        float out = 0.f;
+        if (j < C) {
+          const float craw = cv[e];
+          const float cc = head_clamp<KIND>(craw);
+          float z, d, u;
+          head_z<KIND>(cc, j == y, h, r, z, d, u);
+          // upstream gradient: mean-CE in closed form, or an arbitrary dL/dlogits supplied by autograd
+          const float g = dlogits ? dlogits[(long)n * C + j] : (expf(z - l) - (j == y ? 1.f : 0.f)) * gs;
+          out = head_pass<KIND>(craw) ? g * d : 0.f;
+          if (KIND == FRX_SPHERE) dnorm += g * u;
+          if (KIND == FRX_MAG && j == y) dnorm += g * u * r.aux;      // through the adaptive margin (criterion.py:1264)
+        }
+        ov[e] = out;
       }
-      ov[e] = out;
+      *reinterpret_cast<float4*>(grow + jt) = make_float4(ov[0], ov[1], ov[2], ov[3]);
     }
-    *reinterpret_cast<float4*>(grow + j0) = make_float4(ov[0], ov[1], ov[2], ov[3]);
   }
   if (KIND == FRX_SPHERE || KIND == FRX_MAG) {
     dnorm = block_sum256(dnorm, sh);
@@ -842,6 +876,46 @@ __global__ __launch_bounds__(256) void k_norm_bwd_cols(const float* __restrict__
     for (int u = 0; u < COLU; ++u) {
       const int d = d0 + COLR * u;
       if (d < D) out[(long)d * C + c] = (vd[u] - va[u] * iv * dot) * iv + vo[u];
+    }
+  }
+}
+
+// The same in ONE pass over memory for D <= NB_ROWS * NB_RL (the 512-d embedding): 64 columns x 16 row-lanes per
+// 1024-thread block, a thread's <= 32 rows of both operands stay in registers between the dot product and the output.
+// The two-pass form re-read 2 x 174 MB at C = 85 000 from HBM (a block's 256 KB does not survive in L2): 177 -> ~105 us.
+constexpr int NB_RL = 16, NB_ROWS = 32;
+__global__ __launch_bounds__(1024) void k_norm_bwd_cols_reg(const float* __restrict__ a, const float* __restrict__ dh,
+                                                            const float* __restrict__ inv, int D, int C,
+                                                            float* __restrict__ out, int accumulate) {
+  __shared__ float red[NB_RL][COLB];
+  const int cl = threadIdx.x % COLB, rl = threadIdx.x / COLB;
+  const int c = blockIdx.x * COLB + cl;
+  const bool live = c < C;
+  const float iv = live ? inv[c] : 0.f;
+  float va[NB_ROWS], vd[NB_ROWS];
+  float part = 0.f;
+#pragma unroll
+  for (int u = 0; u < NB_ROWS; ++u) {
+    const int d = rl + NB_RL * u;
+    const bool ok = live && d < D;
+    const long i = ok ? (long)d * C + c : 0;
+    va[u] = ok ? a[i] : 0.f;
+    vd[u] = ok ? dh[i] : 0.f;
+  }
+#pragma unroll
+  for (int u = 0; u < NB_ROWS; ++u) part += va[u] * iv * vd[u];
+  red[rl][cl] = part;
+  __syncthreads();
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < NB_RL; ++i) dot += red[i][cl];
+  if (!live) return;
+#pragma unroll
+  for (int u = 0; u < NB_ROWS; ++u) {
+    const int d = rl + NB_RL * u;
+    if (d < D) {
+      const long i = (long)d * C + c;
+      out[i] = (vd[u] - va[u] * iv * dot) * iv + (accumulate ? out[i] : 0.f);
     }
   }
 }
@@ -1259,6 +1333,9 @@ static int head_bwd_impl(int device, frx_stream_t stream, const frx_head_desc* d
   if (cd)
     hipLaunchKernelGGL(k_norm_bwd_rows, dim3(cdiv(d->C, 4)), dim3(256), 0, st, w, (const float*)W.dwh,
                        (const float*)W.winv, (const float*)nullptr, d->C, d->D, dw, accumulate_dw);
+  else if (d->D <= NB_ROWS * NB_RL)
+    hipLaunchKernelGGL(k_norm_bwd_cols_reg, dim3(cdiv(d->C, COLB)), dim3(1024), 0, st, w, (const float*)W.dwh,
+                       (const float*)W.winv, d->D, d->C, dw, accumulate_dw);
   else
     hipLaunchKernelGGL(k_norm_bwd_cols, dim3(cdiv(d->C, COLB)), dim3(256), 0, st, w, (const float*)W.dwh,
                        (const float*)W.winv, d->D, d->C, dw, accumulate_dw);

@@ -5,7 +5,9 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "face-recognition-models_amd"))
 import torch
-from frx import engine as E, ops
+from frx import engine as E, ops, _lib
+if os.environ.get("FRX_LIB"):          # A/B builds
+    _lib.load_library(os.path.join(ROOT, os.environ["FRX_LIB"]))
 kind = sys.argv[1] if len(sys.argv) > 1 else "curricular"
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 128
 C = int(sys.argv[3]) if len(sys.argv) > 3 else 85000
