@@ -74,3 +74,44 @@ def test_wgrad_group_planning_is_host_logic():
     assert L.frx_wgrad_group_bytes(bad, 2) < 0 and b"dtype" in L.frx_last_error()
     null = (_lib.WgradJob * 1)(_lib.WgradJob(jobs[0].d, None, None, None, 0, 0x2000, None, None, 0x3000))
     assert L.frx_wgrad_group_bytes(null, 1) < 0
+
+
+def test_conv_tile_choice_is_host_logic_and_consistent_with_the_stat_rows():
+    """frx_conv_tile (pure host logic) reports the block tile a launch takes; the partial-statistics row counts the
+    callers allocate by (frx_conv_stat_rows / frx_conv_dgrad_stat_rows) are its M-tile counts.  The ResNet-50 shapes at
+    batch 256 pin the rules of DESIGN.md section 4 (conv_launch.h: pick_tile)."""
+    import ctypes as C
+    from frx import _lib
+    L = _lib.lib()
+
+    def desc(N, H, Ci, Co, k, stride):
+        Ho = (H + 2 * (k // 2) - k) // stride + 1
+        return _lib.ConvDesc(1, N, H, H, Ci, Co, k, k, stride, k // 2, Ho, Ho, 0)
+
+    def tile(d, dgrad):
+        bm, bn = C.c_int(0), C.c_int(0)
+        assert L.frx_conv_tile(C.byref(d), int(dgrad), C.byref(bm), C.byref(bn)) == 0
+        return bm.value, bn.value
+
+    cases = [  # (N, H, Ci, Co, k, stride) -> forward tile, input-gradient tile
+        ((256, 28, 64, 64, 1, 1), (128, 64), (128, 64)),          # 64 output channels
+        ((256, 28, 64, 256, 1, 1), (128, 128), (128, 64)),        # conv3 of layer1; its input gradient has 64 columns
+        ((256, 7, 1024, 256, 1, 1), (64, 128), (128, 128)),       # deep pointwise forward (K = 1024, 392 tiles); conv1-type dgrad
+        ((256, 7, 256, 1024, 1, 1), (128, 128), (64, 128)),       # conv3 of layer3: its input gradient contracts over 1024
+        ((256, 7, 256, 256, 3, 1), (128, 128), (128, 128)),       # 3x3 of layer3
+        ((256, 4, 512, 512, 3, 1), (64, 128), (64, 128)),         # layer4's 3x3 (M = 4096)
+        ((256, 4, 2048, 512, 1, 1), (64, 128), (128, 128)),
+        ((256, 1, 2048, 512, 1, 1), (64, 64), (64, 64)),          # the fc layer as a 1x1 conv
+    ]
+    for shape, fwd, dgr in cases:
+        d = desc(*shape)
+        assert tile(d, False) == fwd, (shape, "fwd", tile(d, False))
+        assert tile(d, True) == dgr, (shape, "dgrad", tile(d, True))
+        m_out, m_in = shape[0] * d.Ho * d.Wo, shape[0] * shape[1] * shape[1]
+        assert L.frx_conv_stat_rows(C.byref(d)) == -(-m_out // fwd[0])
+        assert L.frx_conv_dgrad_stat_rows(C.byref(d)) == -(-m_in // dgr[0])
+    # stride-2 3x3 input gradient: parity-class tiles (four classes, each rounded up)
+    d = desc(256, 14, 256, 256, 3, 2)
+    bm, _ = tile(d, True)
+    per_class = 256 * 7 * 7
+    assert L.frx_conv_dgrad_stat_rows(C.byref(d)) == 4 * -(-per_class // bm)
