@@ -260,8 +260,9 @@ static int wgrad_impl(int device, frx_stream_t stream, const frx_conv_desc* d, c
   return launch_wgrad((hipStream_t)stream, a, d->dtype, g.bt, g.wmode, in_scale != nullptr, pro_y != nullptr, g.tiles * splits);
 }
 
-// ---- grouped launch: table = [njobs] WgradArgs, then [nitems] WgradItem
-static inline size_t group_items_offset(int njobs) { return round_up((long)njobs * (long)sizeof(WgradArgs), 256); }
+// ---- grouped launch: table = [njobs] WgradArgs, 8 draw counters (one per XCD, zero between launches), then [nitems] WgradItem
+static inline size_t group_counters_offset(int njobs) { return round_up((long)njobs * (long)sizeof(WgradArgs), 256); }
+static inline size_t group_items_offset(int njobs) { return group_counters_offset(njobs) + 256; }
 static int group_chunks_per_item() { const char* e = getenv("FRX_WGRAD_GROUP_CHUNKS"); return e ? atoi(e) : 64; }
 
 static int group_build(const frx_wgrad_job* jobs, int njobs, std::vector<WgradArgs>* layers, std::vector<WgradItem>* items) {
@@ -329,13 +330,14 @@ extern "C" int frx_wgrad_group_plan(int device, frx_stream_t stream, const frx_w
   return FRX_OK;
 }
 
-extern "C" int frx_wgrad_group_run(int device, frx_stream_t stream, int dtype, const void* table_dev, int njobs, int nitems,
+extern "C" int frx_wgrad_group_run(int device, frx_stream_t stream, int dtype, void* table_dev, int njobs, int nitems,
                                    int small_tiles) {
   FRX_CHECK_ARG(dtype == FRX_F32 || dtype == FRX_BF16, "wgrad_group_run: dtype");
   FRX_CHECK_ARG(table_dev && njobs > 0 && nitems > 0, "wgrad_group_run: bad args");
   FRX_ENTER(device);
   return launch_wgrad_grouped((hipStream_t)stream, dtype, (const WgradArgs*)table_dev,
-                              (const WgradItem*)((const char*)table_dev + group_items_offset(njobs)), nitems, small_tiles != 0);
+                              (const WgradItem*)((const char*)table_dev + group_items_offset(njobs)), nitems, small_tiles != 0,
+                              (int*)((char*)table_dev + group_counters_offset(njobs)));
 }
 
 extern "C" int frx_conv_wgrad(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x,

@@ -1070,12 +1070,33 @@ enum { WGV_BT128 = 1, WGV_GENERAL = 2, WGV_STEM = 4, WGV_PRO = 8, WGV_YPRO = 16 
 // instantiation -- under 128 registers, four blocks per CU -- instead of the register budget of the widest 128 x 128 variant.
 template <typename T, bool SMALL>
 __global__ __launch_bounds__(256, SMALL ? 4 : 2) void k_wgrad_grouped(const WgradArgs* __restrict__ layers,
-                                                                      const WgradItem* __restrict__ items, int nitems) {
+                                                                      const WgradItem* __restrict__ items, int nitems,
+                                                                      int* __restrict__ counters) {
   __shared__ __attribute__((aligned(16))) char smem[WGRAD_SMEM];
-  for (int it = blockIdx.x; it < nitems; it += gridDim.x) {
+  __shared__ int s_next;
+  // Items are DRAWN, not strided: a block takes the next entry of its XCD's list (item 8 k + xcd, k from an atomic
+  // counter per XCD) whenever it is free.  The tiles of one (layer, split) are adjacent entries, so they start within
+  // one draw of each other whatever the earlier items cost and stream their shared pixel range through that XCD's L2
+  // together; with a fixed stride the blocks drift apart over the rounds.  Every block ends on exactly one failed
+  // draw, so the draw numbered (entries + blocks - 1) is the list's last and re-zeroes the counter for the next launch.
+  const int xcd = blockIdx.x & 7, per_xcd = nitems >> 3, blocks_xcd = gridDim.x >> 3;
+  for (int it = blockIdx.x;; it += gridDim.x) {
+    if (counters) {
+      if (threadIdx.x == 0) {
+        const int k = __hip_atomic_fetch_add(counters + xcd, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (k == per_xcd + blocks_xcd - 1) __hip_atomic_store(counters + xcd, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_next = k;
+      }
+      __syncthreads();
+      const int k = s_next;
+      if (k >= per_xcd) break;
+      it = 8 * k + xcd;
+    } else if (it >= nitems) {
+      break;
+    }
     const WgradItem w = items[it];
     const int li = __builtin_amdgcn_readfirstlane(w.layer);
-    if (li < 0) continue;                 // padding of the XCD-interleaved list
+    if (li < 0) { __syncthreads(); continue; }      // padding of the XCD-interleaved list (barrier: s_next is rewritten next)
     const WgradArgs a = layers[li];
     const int split = __builtin_amdgcn_readfirstlane(w.split), tile = __builtin_amdgcn_readfirstlane(w.tile),
               tap = __builtin_amdgcn_readfirstlane(w.tap);

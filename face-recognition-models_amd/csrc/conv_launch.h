@@ -51,7 +51,8 @@ int launch_igemm_dgrad_plain(hipStream_t st, const ConvArgs& a, int dtype, TileC
 int launch_igemm_dgrad_bn(hipStream_t st, const ConvArgs& a, int dtype, TileCfg c, int grid, int epi, bool add);
 
 int launch_wgrad(hipStream_t st, const WgradArgs& a, int dtype, int bt, int wmode, bool pro, bool ypro, int grid);
-int launch_wgrad_grouped(hipStream_t st, int dtype, const WgradArgs* layers, const WgradItem* items, int nitems, bool small_tiles);
+int launch_wgrad_grouped(hipStream_t st, int dtype, const WgradArgs* layers, const WgradItem* items, int nitems, bool small_tiles,
+                         int* draw_counters);
 
 #define FRX_IGEMM_K(T_, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, ADD_, KC_) \
   hipLaunchKernelGGL((k_igemm<T_, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, ADD_, KC_>), dim3(grid), dim3(64 * WM_ * WN_), igemm_pro_lds(PRO_, a.Kc), st, a)

@@ -21,18 +21,20 @@ int launch_wgrad(hipStream_t st, const WgradArgs& a, int dtype, int bt, int wmod
 }
 // persistent blocks: two per CU (the register budget of the widest variant) -- four for a list of 64 x 64-tile layers only --
 // fewer when the list is short
-int launch_wgrad_grouped(hipStream_t st, int dtype, const WgradArgs* layers, const WgradItem* items, int nitems, bool small_tiles) {
+int launch_wgrad_grouped(hipStream_t st, int dtype, const WgradArgs* layers, const WgradItem* items, int nitems, bool small_tiles,
+                         int* draw_counters) {
+  if (getenv("FRX_WGRAD_STATIC")) draw_counters = nullptr;      // tuning aid: the fixed-stride item order
   const char* e = getenv(small_tiles ? "FRX_WGRAD_GROUP_BLOCKS_SMALL" : "FRX_WGRAD_GROUP_BLOCKS");
   int grid = e ? atoi(e) : (small_tiles ? 1024 : 512);
   if (grid > nitems) grid = nitems;
   grid = grid / 8 * 8;
   if (grid < 8) grid = 8;
   if (dtype == FRX_BF16) {
-    if (small_tiles) hipLaunchKernelGGL((k_wgrad_grouped<bf16_t, true>), dim3(grid), dim3(256), 0, st, layers, items, nitems);
-    else hipLaunchKernelGGL((k_wgrad_grouped<bf16_t, false>), dim3(grid), dim3(256), 0, st, layers, items, nitems);
+    if (small_tiles) hipLaunchKernelGGL((k_wgrad_grouped<bf16_t, true>), dim3(grid), dim3(256), 0, st, layers, items, nitems, draw_counters);
+    else hipLaunchKernelGGL((k_wgrad_grouped<bf16_t, false>), dim3(grid), dim3(256), 0, st, layers, items, nitems, draw_counters);
   } else {
-    if (small_tiles) hipLaunchKernelGGL((k_wgrad_grouped<float, true>), dim3(grid), dim3(256), 0, st, layers, items, nitems);
-    else hipLaunchKernelGGL((k_wgrad_grouped<float, false>), dim3(grid), dim3(256), 0, st, layers, items, nitems);
+    if (small_tiles) hipLaunchKernelGGL((k_wgrad_grouped<float, true>), dim3(grid), dim3(256), 0, st, layers, items, nitems, draw_counters);
+    else hipLaunchKernelGGL((k_wgrad_grouped<float, false>), dim3(grid), dim3(256), 0, st, layers, items, nitems, draw_counters);
   }
   FRX_LAUNCH_CHECK();
   return FRX_OK;

@@ -258,10 +258,11 @@ int64_t frx_wgrad_group_bytes(const frx_wgrad_job* jobs, int njobs);          /*
  * caller, to be kept alive until the copy has run) and copied to `table_dev` by ONE asynchronous copy on `stream`.
  * *small_tiles <- 1 when every job takes the 64 x 64 tile (Co <= 64 or Ci <= 64: layer1, the stem): hand it to
  * frx_wgrad_group_run, which then launches the instantiation that fits four persistent blocks per CU instead of two --
- * so group such layers into a list of their own. */
+ * so group such layers into a list of their own.  The table also holds the launch's eight item-draw counters (one per XCD;
+ * every launch leaves them at zero): one table serves one launch at a time. */
 int frx_wgrad_group_plan(int device, frx_stream_t stream, const frx_wgrad_job* jobs, int njobs, void* table_host,
                          void* table_dev, int64_t table_bytes, int* nitems, int* small_tiles);
-int frx_wgrad_group_run(int device, frx_stream_t stream, int dtype, const void* table_dev, int njobs, int nitems,
+int frx_wgrad_group_run(int device, frx_stream_t stream, int dtype, void* table_dev, int njobs, int nitems,
                         int small_tiles);
 
 /* ---------------------------------------------------------------- backbone: BatchNorm / ReLU / residual / pools
