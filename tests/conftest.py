@@ -30,3 +30,13 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def golden_dir():
     return GOLDEN
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """the one-rank RCCL groups of the GPU stepper / sharded-head tests live for the whole session: close them cleanly"""
+    try:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized():
+            dist.destroy_process_group()
+    except Exception:
+        pass
