@@ -192,9 +192,12 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(long rows, int C, const T
                                                        const float* __restrict__ shift, int relu,
                                                        const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, T* __restrict__ dz_out,
-                                                       float* __restrict__ partial) {
+                                                       float* __restrict__ partial, int g_pool_hw) {
   constexpr int V = Vec16<T>::N;
   __shared__ float red[2][256][V + 1];
+  // g_pool_hw > 0: `g` is the gradient of an average pool over g_pool_hw pixels, [rows / g_pool_hw][C]; each row takes
+  // its image's entry / g_pool_hw, rounded to T as the stand-alone frx_avgpool_bwd stored it
+  const float ginv = g_pool_hw > 0 ? 1.f / (float)g_pool_hw : 1.f;
   const int groups = C / V;                         // channel groups per row
   const int gpb = groups < 256 ? groups : 256;      // groups handled per pass
   const int rpp = 256 / gpb;                        // rows per pass
@@ -214,8 +217,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(long rows, int C, const T
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
           const long rr = r + u * stride;
-          const long i = (rr < rows ? rr : r) * groups + grp;
-          vg[u].raw = reinterpret_cast<const uint4*>(g)[i];
+          const long rc = rr < rows ? rr : r, i = rc * groups + grp;
+          vg[u].raw = reinterpret_cast<const uint4*>(g)[g_pool_hw > 0 ? (rc / g_pool_hw) * groups + grp : i];
           vy[u].raw = reinterpret_cast<const uint4*>(y)[i];
           if (out) vo[u].raw = reinterpret_cast<const uint4*>(out)[i];
         }
@@ -223,6 +226,10 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(long rows, int C, const T
         for (int u = 0; u < RU; ++u) {
           const long rr = r + u * stride;
           const bool live = rr < rows;
+          if (g_pool_hw > 0) {
+#pragma unroll
+            for (int j = 0; j < V; ++j) vg[u].set(j, vg[u].get(j) * ginv);
+          }
           Vec16<T> vz;
 #pragma unroll
           for (int j = 0; j < V; ++j) {
@@ -656,9 +663,10 @@ extern "C" int frx_bn_bwd_partial_rows(int64_t rows, int C) {
 
 extern "C" int frx_bn_bwd_reduce(int device, frx_stream_t stream, int dtype, int64_t rows, int C, const void* g,
                                  const void* y, const void* out, const float* scale, const float* shift, int relu,
-                                 const float* mean, const float* invstd, void* dz_out, float* partial) {
+                                 const float* mean, const float* invstd, void* dz_out, float* partial, int g_pool_hw) {
   FRX_DT_CHECK(dtype);
   FRX_CHECK_ARG(g && y && mean && invstd && partial && rows > 0, "bn_bwd_reduce: bad args");
+  FRX_CHECK_ARG(g_pool_hw >= 0 && (g_pool_hw == 0 || rows % g_pool_hw == 0), "bn_bwd_reduce: rows=%ld is not a multiple of g_pool_hw=%d", (long)rows, g_pool_hw);
   const int V = FRX_VEC(dtype), groups = C / V;
   FRX_CHECK_ARG(C % V == 0 && (groups >= 256 ? groups % 256 == 0 : 256 % groups == 0),
                 "bn_bwd_reduce: C=%d must give a power-of-two number of 16-byte groups", C);
@@ -668,11 +676,11 @@ extern "C" int frx_bn_bwd_reduce(int device, frx_stream_t stream, int dtype, int
   if (dtype == FRX_BF16)
     hipLaunchKernelGGL(k_bn_bwd_reduce<bf16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (long)rows, C,
                        (const bf16_t*)g, (const bf16_t*)y, (const bf16_t*)out, scale, shift, relu, mean, invstd,
-                       (bf16_t*)dz_out, partial);
+                       (bf16_t*)dz_out, partial, g_pool_hw);
   else
     hipLaunchKernelGGL(k_bn_bwd_reduce<float>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (long)rows, C,
                        (const float*)g, (const float*)y, (const float*)out, scale, shift, relu, mean, invstd,
-                       (float*)dz_out, partial);
+                       (float*)dz_out, partial, g_pool_hw);
   FRX_LAUNCH_CHECK();
   return FRX_OK;
 }

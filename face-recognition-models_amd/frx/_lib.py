@@ -83,7 +83,7 @@ _SIGS = {
     "frx_block_merge_fwd_mask": (C.c_int, [C.c_int, _P, C.c_int, C.c_int64, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P]),
     "frx_bn_bwd_partial_rows": (C.c_int, [C.c_int64, C.c_int]),
     "frx_bn_bwd_reduce": (C.c_int, [C.c_int, _P, C.c_int, C.c_int64, C.c_int, _P, _P, _P, _P, _P, C.c_int,
-                                    _P, _P, _P, _P]),
+                                    _P, _P, _P, _P, C.c_int]),
     "frx_bn_bwd_finalize": (C.c_int, [C.c_int, _P, _P, C.c_int, C.c_int, C.c_int64, _P, _P, _P, _P, _P, _P]),
     "frx_bn_bwd_apply": (C.c_int, [C.c_int, _P, C.c_int, C.c_int64, C.c_int, _P, _P, _P, _P, _P, C.c_int,
                                    _P, _P, _P, _P]),

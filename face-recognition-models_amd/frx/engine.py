@@ -426,13 +426,12 @@ class ResNet50Engine:
         dpool = self._like(S[4], self.pooled)
         ops.conv_dgrad(self.fc_desc, self.dfeat_t, self.fc_wt, dpool)
         last = self.blocks[-1]
-        g = self._like(S[3], last.out)
-        ops.avgpool_bwd(dt, N, self.h_final * self.h_final, 2048, dpool, g)
-        # last block: its output gradient comes from the pool, so mask + reduce run stand-alone
+        # last block: its output gradient comes from the average pool, so mask + reduce run stand-alone; the reduce
+        # broadcasts the pooled gradient itself (no [N, 4, 4, 2048] tensor, no launch for it)
         c3 = last.conv3
         rows3 = c3.y.numel() // c3.Co
-        ops.bn_bwd_reduce(dt, rows3, c3.Co, g, c3.y, self._bn(self.bn_mean, c3), self._bn(self.bn_invstd, c3),
-                          self.bwd_partial, out=last.out, dz_out=last.dz3)
+        ops.bn_bwd_reduce(dt, rows3, c3.Co, dpool, c3.y, self._bn(self.bn_mean, c3), self._bn(self.bn_invstd, c3),
+                          self.bwd_partial, out=last.out, dz_out=last.dz3, g_pool_hw=self.h_final * self.h_final)
         self._bw_npart = ops.bn_bwd_partial_rows(rows3, c3.Co)
         self._backward_blocks(len(self.blocks) - 1, self.SPLIT_BLOCK)
         self._run_wgrad_group(0)

@@ -424,9 +424,11 @@ def bn_bwd_partial_rows(rows, Cc):
     return _lib.lib().frx_bn_bwd_partial_rows(rows, Cc)
 
 
-def bn_bwd_reduce(dtype, rows, Cc, g, y, mean, invstd, partial, out=None, scale=None, shift=None, relu=False, dz_out=None):
+def bn_bwd_reduce(dtype, rows, Cc, g, y, mean, invstd, partial, out=None, scale=None, shift=None, relu=False, dz_out=None,
+                  g_pool_hw=0):
+    """g_pool_hw > 0: g is the [rows / g_pool_hw, C] gradient of an average pool, broadcast (and divided) on the fly"""
     check(_lib.lib().frx_bn_bwd_reduce(_dev(g), _stream(g), dtype, rows, Cc, _p(g), _p(y), _p(out), _p(scale),
-                                       _p(shift), int(relu), _p(mean), _p(invstd), _p(dz_out), _p(partial)),
+                                       _p(shift), int(relu), _p(mean), _p(invstd), _p(dz_out), _p(partial), int(g_pool_hw)),
           "frx_bn_bwd_reduce")
 
 

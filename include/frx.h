@@ -290,9 +290,11 @@ int frx_block_merge_fwd_mask(int device, frx_stream_t stream, int dtype, int64_t
  *               gam = alpha*(mu*invstd*mean(dz*xhat) - mean(dz))
  *   apply    -> dy = alpha*dz + beta*y + gam   (or fused into the consumers: frx_conv_dgrad_bn / frx_conv_wgrad_bn) */
 int frx_bn_bwd_partial_rows(int64_t rows, int C);
+/* g_pool_hw > 0: `g` is the gradient of an average pool over g_pool_hw pixels, [rows / g_pool_hw][C]; every row takes its
+ * image's entry / g_pool_hw (what frx_avgpool_bwd would have stored, without that tensor in memory).  0: g is [rows][C]. */
 int frx_bn_bwd_reduce(int device, frx_stream_t stream, int dtype, int64_t rows, int C, const void* g, const void* y,
                       const void* out, const float* scale, const float* shift, int relu, const float* mean,
-                      const float* invstd, void* dz_out, float* partial);
+                      const float* invstd, void* dz_out, float* partial, int g_pool_hw);
 int frx_bn_bwd_finalize(int device, frx_stream_t stream, const float* partial, int nblk, int C, int64_t count,
                         const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
                         float* coef);

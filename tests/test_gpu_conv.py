@@ -393,3 +393,28 @@ def test_fused_stem_backward(dtype, geom):
         want = (gamma.cpu() * invstd.cpu()).view(1, -1, 1, 1) * (dz - m1 - xhat * m2)
         _close(dy, want.permute(0, 2, 3, 1), dtype, "fused dy vs ATen")
         assert (dbe2.cpu() - dz.sum((0, 2, 3))).abs().max().item() < 1e-3 and (dga2.cpu() - (dz * xhat).sum((0, 2, 3))).abs().max().item() < 1e-3
+
+
+@pytest.mark.parametrize("dtype", [0, 1], ids=["f32", "bf16"])
+def test_bn_bwd_reduce_broadcasts_a_pooled_gradient(dtype):
+    """frx_bn_bwd_reduce(g_pool_hw = HW) on the [N, C] gradient of an average pool == frx_avgpool_bwd followed by the plain
+    reduce, bit for bit (same dz, same partial sums) -- without the broadcast tensor in memory."""
+    from frx import ops
+    N, HW, Cc = 6, 16, 256
+    T = ops.TORCH_DT[dtype]
+    dpool = _mk(dtype, N, Cc, seed=1).to(DEV)
+    y = _mk(dtype, N * HW, Cc, seed=2).to(DEV)
+    out = torch.relu(_mk(dtype, N * HW, Cc, seed=3)).to(DEV)
+    g = torch.Generator().manual_seed(4)
+    mean, invstd = (torch.randn(Cc, generator=g) * 0.2).to(DEV), (torch.rand(Cc, generator=g) + 0.5).to(DEV)
+    rows = N * HW
+    nblk = ops.bn_bwd_partial_rows(rows, Cc)
+    gfull = torch.empty(rows, Cc, dtype=T, device=DEV)
+    ops.avgpool_bwd(dtype, N, HW, Cc, dpool, gfull)
+    p_ref, dz_ref = torch.zeros(nblk, 2, Cc, device=DEV), torch.empty_like(gfull)
+    ops.bn_bwd_reduce(dtype, rows, Cc, gfull, y, mean, invstd, p_ref, out=out, dz_out=dz_ref)
+    p, dz = torch.zeros_like(p_ref), torch.empty_like(gfull)
+    ops.bn_bwd_reduce(dtype, rows, Cc, dpool, y, mean, invstd, p, out=out, dz_out=dz, g_pool_hw=HW)
+    torch.cuda.synchronize()
+    assert torch.equal(dz, dz_ref) and torch.equal(p, p_ref)
+    assert (dz_ref.float().abs().sum() > 0) and (dz_ref == 0).any()
