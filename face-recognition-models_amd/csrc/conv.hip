@@ -268,6 +268,8 @@ static int group_chunks_per_item() { const char* e = getenv("FRX_WGRAD_GROUP_CHU
 static int group_build(const frx_wgrad_job* jobs, int njobs, std::vector<WgradArgs>* layers, std::vector<WgradItem>* items) {
   FRX_CHECK_ARG(jobs && njobs > 0, "wgrad_group: no jobs");
   const int target = group_chunks_per_item();
+  const char* es = getenv("FRX_WGRAD_SCATTER_CHUNKS");
+  const int scatter_chunks = es ? atoi(es) : 128;
   // (layer, split) groups stream the same pixel range: keep each on ONE XCD (block b runs on XCD b % 8, item p is
   // taken by block p % grid), so its tiles share that L2.  Groups go round-robin to the least loaded XCD list.
   std::vector<std::vector<WgradItem>> xl(8);
@@ -287,6 +289,15 @@ static int group_build(const frx_wgrad_job* jobs, int njobs, std::vector<WgradAr
     for (int sp = 0; sp < splits; ++sp) {
       int best = 0;
       for (int x = 1; x < 8; ++x) if (load[x] < load[best]) best = x;
+      // ... unless the layer has few pixels and many tiles (layer4: 4096 pixels, up to 144 tiles per split): its operands
+      // are small and L2-resident anyway, and a whole (layer, split) group on one list leaves the eight lists unbalanced
+      // (the launch ends with the longest).  Those tiles go round-robin over the XCDs (upper list 563 -> 513 us).
+      if (g.nchunks <= scatter_chunks) {
+        int q = 0;
+        for (int tap = 0; tap < g.taps; ++tap)
+          for (int t = 0; t < a.tilesCo * a.tilesCi; ++t, ++q) { xl[(best + q) & 7].push_back(WgradItem{li, sp, t, tap}); load[(best + q) & 7] += cost; }
+        continue;
+      }
       for (int tap = 0; tap < g.taps; ++tap)
         for (int t = 0; t < a.tilesCo * a.tilesCi; ++t) xl[best].push_back(WgradItem{li, sp, t, tap});
       load[best] += cost * g.tiles;
