@@ -421,7 +421,8 @@ class ResNet50Engine:
         S = self.scratch
         # fc
         ops.cast(dt, dfeat, self.dfeat_t, to_f32=False)
-        ops.conv_wgrad(self.fc_desc, self.pooled, self.dfeat_t, self.fc_w(self.grads))
+        if not self.grouped_wgrad:          # (grouped: the fc layer's weight gradient is one more job of the upper list --
+            ops.conv_wgrad(self.fc_desc, self.pooled, self.dfeat_t, self.fc_w(self.grads))     # its own launch cost 34 us for 64 tiles)
         ops.colsum_f32(dfeat, self.fc_b(self.grads))
         dpool = self._like(S[4], self.pooled)
         ops.conv_dgrad(self.fc_desc, self.dfeat_t, self.fc_wt, dpool)
@@ -562,6 +563,7 @@ class ResNet50Engine:
                     jobs.append(self._wgrad_job(c, x, dz, x_bn=xb, pro_y=c.y, pro_coef=coef))
             jobs.append(self._wgrad_job(b.conv2, b.conv1.y, b.dy2, x_bn=b.conv1))
         groups[2].append(self._wgrad_job(self.stem, self.xin, self.dy_stem))
+        groups[0].append(dict(d=self.fc_desc, x=self.pooled, dy=self.dfeat_t, dw=self.fc_w(self.grads), pro_y=None, pro_coef=None))
         self._wg_groups = [ops.wgrad_group_plan(self.dtype, jobs) for jobs in groups]
 
     def _run_wgrad_group(self, which):
