@@ -64,6 +64,18 @@ def cpu_baseline(threads, max_seconds=25.0):
                       f"fp32, torch CPU oracle, {dt:.1f}s"}
 
 
+def baseline_config(args, world):
+    """which BASELINE.json config (if any) the arguments of this run describe -- the workload string follows the run"""
+    key = (args.head, args.classes, args.batch, args.dtype, bool(args.shard_head))
+    if key == ("arcface", 10575, 256, "bf16", False):
+        return "BASELINE configs[1]" + ("" if world == 1 else f" per-GPU shape on {world} GPUs")
+    if key == ("cosface", 10575, 256, "bf16", False):
+        return "BASELINE configs[2]" + (" per-GPU shape" if world != 8 else "")
+    if args.head == "curricular" and args.classes in (85000, 85742) and args.batch == 128 and args.dtype == "bf16":
+        return "BASELINE configs[3]" + (" per-GPU shape" if world != 8 else "") + (", class-sharded head" if args.shard_head else "")
+    return "not a BASELINE config (custom --head / --classes / --batch / --dtype)"
+
+
 def kernel_pass(eng, images, labels, steps=3):
     """Per-launch HIP-event timing of the GEMM-class kernels over `steps` eager steps.  Each launch is bracketed by
     events on its own stream; a launch's duration is the MINIMUM over the steps (an eager step is host-paced, so a
@@ -275,7 +287,7 @@ def run(args):
             "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"{args.head} ResNet-50 (torchvision v1.5 topology, fc->512), {args.classes}-class head, "
                                    f"bs={args.batch}/GPU, 112x112, fwd+CE+bwd+SGD(momentum 0.9, wd 5e-4), "
-                                   f"random-init weights, BASELINE configs[1]",
+                                   f"random-init weights, {baseline_config(args, world)}",
                        "global_batch": world * args.batch, "parallelism": f"dp{world}",
                        "hip_graph": bool(graph), "graph_segments": len(stepper.segments()) if graph else 0,
                        "bf16_grad_buckets": bool(stepper.bf16), "class_sharded_head": bool(args.shard_head),

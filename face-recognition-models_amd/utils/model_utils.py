@@ -155,10 +155,21 @@ def _epoch_checkpoints(path, name):
     return sorted(found)
 
 
+def _dist_rank_world():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
 def load_latest_checkpoint(model, optimizer, scheduler, scaler, model_checkpoints_path, model_name, device,
                            isCheckpoint=True):
     """-> (start_epoch, train_loss | None); newest epoch checkpoint, or the min-loss one (which also
-    removes the epoch checkpoints, as upstream does, model_utils.py:113-117)."""
+    removes the epoch checkpoints, as upstream does, model_utils.py:113-117).
+    Data parallel: every rank loads, but the directory is listed BEFORE anything is removed and only rank 0 removes
+    (after a barrier, so no rank is still listing); a second barrier keeps a rank from saving into a directory that is
+    being pruned."""
+    rank, world = _dist_rank_world()
     epochs = _epoch_checkpoints(model_checkpoints_path, model_name)
     path = None
     if isCheckpoint:
@@ -166,9 +177,16 @@ def load_latest_checkpoint(model, optimizer, scheduler, scaler, model_checkpoint
     else:
         best = os.path.join(model_checkpoints_path, f"{model_name}_min_loss.pth")
         if os.path.exists(best):
-            for _, f in epochs:
-                os.remove(f)
             path = best
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        if path is not None and rank == 0:
+            for _, f in epochs:
+                if os.path.exists(f):
+                    os.remove(f)
+        if world > 1:
+            dist.barrier()
     if path is None:
         return 1, None
     ck = torch.load(path, map_location="cpu", weights_only=True)
@@ -259,6 +277,7 @@ def train_model(model, train_loader, criterion, optimizer, scaler, device, epoch
     # (loss_g is the integer 0 for every head but MagFace, whose fused backward takes lambda_g itself)
     fused = isinstance(model, NativeFaceNet) and isinstance(optimizer, FusedSGD) and _is_plain_ce(criterion)
     lambda_g = float(getattr(args, "lambda_g", 0.0))
+    lead = _dist_rank_world()[0] == 0
     _ITERS["n"] += 1
     pending = []                 # (device loss, device top-k counts, batch size) not yet synced to the host
     end = time.time()
@@ -271,8 +290,9 @@ def train_model(model, train_loader, criterion, optimizer, scaler, device, epoch
             a1, a5 = (float(v) * 100.0 / n for v in topk_t.tolist())
             meters["loss"].update(lv, n); meters["lid"].update(lid, n); meters["lmag"].update(mag, n)
             meters["a1"].update(a1, n); meters["a5"].update(a5, n)
-            wandb.log({"loss": lv, "loss_id": lid, "loss_mag": mag, "acc1": a1, "acc5": a5, "lr": lr, "epoch": epoch,
-                       "step": _ITERS["n"]}, step=_ITERS["n"])
+            if lead:                # (wandb.init ran on rank 0 only: main_pipeline)
+                wandb.log({"loss": lv, "loss_id": lid, "loss_mag": mag, "acc1": a1, "acc5": a5, "lr": lr, "epoch": epoch,
+                           "step": _ITERS["n"]}, step=_ITERS["n"])
             _ITERS["n"] += 1
         pending.clear()
 
@@ -316,8 +336,9 @@ def train_model(model, train_loader, criterion, optimizer, scaler, device, epoch
             mag = args.lambda_g * (loss_g.item() if isinstance(loss_g, torch.Tensor) else loss_g)
             meters["loss"].update(lv, n); meters["lid"].update(lidv, n); meters["lmag"].update(mag, n)
             meters["a1"].update(acc1[0].item(), n); meters["a5"].update(acc5[0].item(), n)
-            wandb.log({"loss": lv, "loss_id": lidv, "loss_mag": mag, "acc1": acc1[0].item(), "acc5": acc5[0].item(),
-                       "lr": lr, "epoch": epoch, "step": _ITERS["n"]}, step=_ITERS["n"])
+            if lead:
+                wandb.log({"loss": lv, "loss_id": lidv, "loss_mag": mag, "acc1": acc1[0].item(), "acc5": acc5[0].item(),
+                           "lr": lr, "epoch": epoch, "step": _ITERS["n"]}, step=_ITERS["n"])
             _ITERS["n"] += 1
         now = time.time()
         meters["bt"].update(now - end)

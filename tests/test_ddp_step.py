@@ -151,3 +151,91 @@ def test_segments_follow_the_exchange_points():
     assert st.segments() == [["forward"], ["upper"], ["lower"], ["update"]]
     eng.exchange_ty = False
     assert st.segments() == [["forward", "upper"], ["lower"], ["update"]]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# main_pipeline's data-parallel housekeeping (Weak 11): the min-loss resume prunes the epoch checkpoints
+# (model_utils.py:113-117 upstream) -- with several ranks only rank 0 may remove files, and nobody may still be listing
+# the directory; wandb.init runs on rank 0 only (main_pipeline), so wandb.log on another rank raises with the real package.
+# ------------------------------------------------------------------------------------------------------------------
+class _StrictWandb:
+    """stand-in for the real package: log() before init() raises (wandb.errors.Error upstream)"""
+    def __init__(self):
+        self.inited, self.logs = False, []
+
+    def init(self, **kw):
+        self.inited = True
+
+    def log(self, d, step=None):
+        if not self.inited:
+            raise RuntimeError("You must call wandb.init() before wandb.log()")
+        self.logs.append(dict(d))
+
+
+def _housekeeping_worker(rank, world, port, q, ckdir):
+    import types
+    import torch.distributed as dist
+    import torch.nn as nn
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from utils import model_utils as MU
+    from utils.schedulers import get_scheduler
+    net = nn.Linear(4, 3)
+    opt = torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9)
+    sch = get_scheduler(opt, "customstep")
+    # every rank resumes from the min-loss checkpoint at the same time
+    start, loss = MU.load_latest_checkpoint(net, opt, sch, None, ckdir, "M", "cpu", isCheckpoint=False)
+    left = sorted(os.listdir(ckdir))
+    # the loop's logging: only the rank that called wandb.init may log
+    MU.wandb = _StrictWandb()
+    if rank == 0:
+        MU.wandb.init(project="p")
+
+    class Toy(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.fc = nn.Linear(4, 3)
+
+        def forward(self, x, labels=None):
+            z = self.fc(x)
+            return [z, z], z.norm(dim=1, keepdim=True), 0, None
+    toy = Toy()
+    g = torch.Generator().manual_seed(rank)
+    batches = [(torch.randn(5, 4, generator=g), torch.randint(0, 3, (5,), generator=g)) for _ in range(3)]
+    args = types.SimpleNamespace(lambda_g=0.0, print_freq=1)
+    MU._ITERS["n"] = -1
+    avg = MU.train_model(toy, batches, nn.CrossEntropyLoss(), torch.optim.SGD(toy.parameters(), lr=0.1), MU.GradScaler(enabled=False),
+                         torch.device("cpu"), 1, 1, args)
+    q.put((rank, start, loss, left, len(MU.wandb.logs), float(avg)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_min_loss_resume_and_logging_with_two_ranks(tmp_path):
+    import torch.multiprocessing as mp
+    import torch.nn as nn
+    from utils import model_utils as MU
+    from utils.schedulers import get_scheduler
+    net = nn.Linear(4, 3)
+    opt = torch.optim.SGD(net.parameters(), lr=0.1, momentum=0.9)
+    sch = get_scheduler(opt, "customstep")
+    d = str(tmp_path / "ck")
+    for e in range(1, 5):
+        MU.save_checkpoint(net, opt, sch, None, 1.0 / e, e, d, "M", isCheckpoint=True)
+    MU.save_checkpoint(net, opt, sch, None, 0.25, 4, d, "M", isCheckpoint=False)
+    assert len(os.listdir(d)) == 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() * 11 + 5) % 2000
+    procs = [ctx.Process(target=_housekeeping_worker, args=(r, 2, port, q, d)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=180) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for rank, start, loss, left, nlogs, avg in res:
+        assert (start, loss) == (5, pytest.approx(0.25)), "every rank resumes from the same min-loss checkpoint"
+        assert left == ["M_min_loss.pth"], "epoch checkpoints pruned exactly once, after every rank had listed them"
+        assert nlogs == (3 if rank == 0 else 0), "only the rank that ran wandb.init logs"
+        assert avg == avg

@@ -42,12 +42,39 @@ def _close(got, ref, dtype, what):
     assert err <= atol * scale + 1e-6, f"{what}: max err {err:.3e} vs scale {scale:.3e}"
 
 
+def _sid(s):
+    return f"{s[0]}x{s[1]}k{s[2]}s{s[3]}h{s[4]}"
+
+
+# The instantiated k_igemm tiles ("BMxBNxWAVESxKC", csrc/conv_launch.h).  pick_tile() chooses by the number of tiles a
+# launch has, so a 3-image test only ever reaches the small ones: FRX_IGEMM_TILE (read per launch) forces each
+# production tile through the same ATen comparisons, and test_conv_production_size_vs_aten runs the shapes at the
+# bench's own batch, where pick_tile makes the choice itself.
+TILES = ["128x128x8x64", "64x128x4x128", "128x64x4x64", "64x64x4x64"]
+TILE_SHAPES = [(64, 256, 1, 1, 28), (256, 64, 1, 1, 28), (128, 128, 3, 1, 14), (128, 128, 3, 2, 28), (256, 512, 1, 2, 28),
+               (1024, 256, 1, 1, 7), (256, 256, 3, 1, 7), (512, 512, 3, 2, 7), (512, 512, 3, 1, 4), (2048, 512, 1, 1, 4)]
+
+
 @pytest.mark.parametrize("dtype", [0, 1], ids=["f32", "bf16"])
-@pytest.mark.parametrize("shape", SHAPES, ids=[f"{s[0]}x{s[1]}k{s[2]}s{s[3]}h{s[4]}" for s in SHAPES])
+@pytest.mark.parametrize("shape", SHAPES, ids=[_sid(s) for s in SHAPES])
 def test_conv_fwd_dgrad_wgrad(dtype, shape):
+    _conv_case(dtype, shape, 3)
+
+
+@pytest.mark.parametrize("dtype", [0, 1], ids=["f32", "bf16"])
+@pytest.mark.parametrize("tile", TILES)
+@pytest.mark.parametrize("shape", TILE_SHAPES, ids=[_sid(s) for s in TILE_SHAPES])
+def test_conv_forced_tiles_vs_aten(monkeypatch, dtype, shape, tile):
+    """every instantiated tile (eight-wave 128x128, 64x128 with 128-byte K-chunks, 128x64, 64x64) on forward, input
+    gradient (incl. the stride-2 parity-class path) and their epilogues, batch 9: several row tiles and a ragged tail"""
+    monkeypatch.setenv("FRX_IGEMM_TILE", tile)
+    _conv_case(dtype, shape, 9)
+
+
+def _conv_case(dtype, shape, N):
     from frx import ops
     Ci, Co, k, stride, Hi = shape
-    N, pad = 3, k // 2
+    pad = k // 2
     d = ops.conv_desc(dtype, N, Hi, Hi, Ci, Co, k, k, stride, pad)
     x = _mk(dtype, N, Hi, Hi, Ci, seed=1)                       # NHWC
     w = _mk(dtype, Co, k, k, Ci, scale=(Ci * k * k) ** -0.5, seed=2)   # KRSC
@@ -91,6 +118,29 @@ def test_conv_fwd_dgrad_wgrad(dtype, shape):
     refdw = torch.nn.grad.conv2d_weight(xin.permute(0, 3, 1, 2), (Co, Ci, k, k), dy.float().permute(0, 3, 1, 2),
                                         stride=stride, padding=pad).permute(0, 2, 3, 1) + 0.5
     _close(dw, refdw, dtype, "conv_wgrad")
+
+
+PROD_SHAPES = [((256, 256, 3, 1, 7), (128, 128)), ((512, 512, 3, 1, 4), (64, 128)), ((1024, 256, 1, 1, 7), (64, 128)),
+               ((128, 128, 3, 2, 28), (128, 128)), ((64, 256, 1, 1, 28), (128, 128)), ((256, 64, 1, 1, 28), (128, 64))]
+
+
+@pytest.mark.parametrize("shape,tile", PROD_SHAPES, ids=[_sid(s) for s, _ in PROD_SHAPES])
+def test_conv_production_size_vs_aten(shape, tile):
+    """BASELINE configs[1]'s own launches: batch 256, bf16, the tile pick_tile() chooses at that size (asserted), forward
+    with prologue and statistics, input gradient with addend, weight gradient -- all against ATen CPU fp32"""
+    from frx import ops
+    Ci, Co, k, stride, Hi = shape
+    d = ops.conv_desc(ops.BF16, 256, Hi, Hi, Ci, Co, k, k, stride, k // 2)
+    assert ops._igemm_tile(d) == tile, "pick_tile no longer chooses the tile this test was written for"
+    _conv_case(ops.BF16, shape, 256)
+
+
+@pytest.mark.parametrize("shape", [(1024, 256, 1, 1, 7), (256, 256, 3, 1, 7), (256, 64, 1, 1, 28), (256, 256, 3, 2, 14)], ids=_sid)
+@pytest.mark.parametrize("merge_mask", [False, True], ids=["relu_bn_mask", "merge_mask"])
+def test_fused_bn_backward_production_size(shape, merge_mask):
+    """the fused BN-backward input / weight gradients at batch 256, bf16, on the tiles the bench runs them on"""
+    from frx import ops
+    _fused_bn_case(ops.BF16, shape, merge_mask, 256)
 
 
 @pytest.mark.parametrize("dtype", [0, 1], ids=["f32", "bf16"])
@@ -159,9 +209,29 @@ def test_fc_as_conv(dtype):
 @pytest.mark.parametrize("merge_mask", [False, True], ids=["relu_bn_mask", "merge_mask"])
 def test_fused_bn_backward_in_dgrad_wgrad(dtype, shape, merge_mask):
     """frx_conv_dgrad_bn / frx_conv_wgrad_bn == (bn_bwd_apply -> dgrad -> bn_bwd_reduce) and (apply -> wgrad)."""
+    _fused_bn_case(dtype, shape, merge_mask, 3)
+
+
+FUSED_TILE_SHAPES = [(64, 256, 1, 1, 28), (256, 64, 1, 1, 28), (512, 128, 1, 1, 14), (128, 128, 3, 1, 14), (2048, 512, 1, 1, 4),
+                     (256, 256, 3, 2, 14), (1024, 256, 1, 1, 7)]
+
+
+@pytest.mark.parametrize("dtype", [0, 1], ids=["f32", "bf16"])
+@pytest.mark.parametrize("tile", TILES)
+@pytest.mark.parametrize("shape", FUSED_TILE_SHAPES, ids=[_sid(s) for s in FUSED_TILE_SHAPES])
+@pytest.mark.parametrize("merge_mask", [False, True], ids=["relu_bn_mask", "merge_mask"])
+def test_fused_bn_backward_forced_tiles(monkeypatch, dtype, shape, merge_mask, tile):
+    """the BN-backward prologue (PRO = 2, with the dy side store), the masking / reducing epilogues (EPI_BNBWD,
+    EPI_BNBWD_OUT with byte masks) and the addend on every instantiated tile.  The reference composition below runs
+    under the same forced tile; its plain dgrad is itself held to ATen by test_conv_forced_tiles_vs_aten."""
+    monkeypatch.setenv("FRX_IGEMM_TILE", tile)
+    _fused_bn_case(dtype, shape, merge_mask, 9)
+
+
+def _fused_bn_case(dtype, shape, merge_mask, N):
     from frx import ops
     Ci, Co, k, stride, Hi = shape
-    N, pad = 3, k // 2
+    pad = k // 2
     d = ops.conv_desc(dtype, N, Hi, Hi, Ci, Co, k, k, stride, pad)
     T = ops.TORCH_DT[dtype]
     dz = _mk(dtype, N, d.Ho, d.Wo, Co, seed=1).to(DEV)           # masked upstream gradient of THIS conv's BN
@@ -250,12 +320,15 @@ def test_conv_many_coresident_blocks(dtype, shape):
 
 @pytest.mark.parametrize("dtype", [0, 1], ids=["f32", "bf16"])
 @pytest.mark.parametrize("shape", [(256, 128, 28), (512, 256, 14), (64, 64, 9)], ids=lambda s: f"{s[0]}x{s[1]}h{s[2]}")
-def test_dgrad_compact_stride2_addend(dtype, shape):
+@pytest.mark.parametrize("tile", [None] + TILES)
+def test_dgrad_compact_stride2_addend(monkeypatch, dtype, shape, tile):
     """addend_stride = 2: the compact [N,ceil(H/2),ceil(W/2),Ci] gradient of a stride-2 1x1 branch is added at the even
     pixels -- identical to adding its zero-filled full-size form (odd H covers the ceil)."""
     from frx import ops
     Ci, Co, Hi = shape
-    N = 3
+    N = 3 if tile is None else 9
+    if tile is not None:
+        monkeypatch.setenv("FRX_IGEMM_TILE", tile)
     d = ops.conv_desc(dtype, N, Hi, Hi, Ci, Co, 1, 1, 1, 0)
     T = ops.TORCH_DT[dtype]
     dz = _mk(dtype, N, Hi, Hi, Co, seed=1).to(DEV)

@@ -37,15 +37,16 @@ def _grad_of(eng, ref, name):
 
 @pytest.mark.parametrize("kind", ["arcface", "curricular"])
 def test_train_steps_fp32_vs_oracle(kind):
-    """BASELINE config-1 shape family (ArcFace R50, 100 identities) at a CPU-friendly batch.
+    """BASELINE configs[0] itself: ArcFace R50, 512-d embeddings, 100 synthetic identities, batch 32, fp32 parity mode
+    against the CPU oracle's train step (and the CurricularFace head on the same shape).
 
     Forward: embeddings / logits / loss within the north-star 1e-3 of the fp32 CPU oracle.
     Backward: fp32 gradients of this network are ill-conditioned (logits x64, ReLU-mask flips, batch
-    statistics over 8 samples): the fp32 CPU oracle itself sits 2-20 % (max-norm) from a float64
+    statistics over 32 samples): the fp32 CPU oracle itself sits 2-20 % (max-norm) from a float64
     run (scripts/diag_grads.py).  So gradients are judged against a float64 oracle and must be as
     close to it as the fp32 CPU oracle is."""
     from frx import ops
-    N, C, lr = 8, 100, 0.01
+    N, C, lr = 32, 100, 0.01
     ref, eng = _pair(kind, N, C, ops.F32, seed=1)
     mom_expect = torch.zeros_like(eng.net.params)
     ref64 = FaceNet(KINDS[kind], C)

@@ -141,6 +141,37 @@ def test_head_full_size_properties(name, N, Cc):
     assert rad < 1e-4 * dx.abs().max().item() * x.norm(dim=1).max().item() + 1e-6
 
 
+@pytest.mark.parametrize("name,N,Cc", [("curricular", 128, 85742), ("arcface", 64, 85742)])
+def test_head_ragged_85742_vs_float64_oracle(name, N, Cc):
+    """configs[3]'s second width (85 742 identities = 2 x 43 x 997, no tile multiple) at full size,
+    both weight layouts, against the float64 oracle: logits / cosines within the north-star 1e-3, loss, lse, top-k,
+    dX and dW within 1e-3 of their scale, CurricularFace's EMA."""
+    kind = KINDS[name]
+    D = 512
+    rng = np.random.RandomState(85742 + N)
+    wshape = (Cc, D) if H.weight_is_cd(kind) else (D, Cc)
+    w = (rng.randn(*wshape) * 0.05).astype(np.float32)
+    y = rng.randint(0, Cc, N)
+    y[:4] = [0, Cc - 1, Cc - 2, 85696]          # first / last columns, and the first column of the ragged last tile
+    x = rng.randn(N, D).astype(np.float32)
+    wc = w if H.weight_is_cd(kind) else w.T
+    for i in range(0, N, 3):
+        x[i] = wc[y[i]] / np.linalg.norm(wc[y[i]]) * 4 + 0.3 * rng.randn(D)
+    hy = H.HeadHyper.default(kind)
+    st = H.HeadState(iter=6, t=0.123)
+    ref = H.head_forward_backward(kind, x, w, y, hy, st, dtype=np.float64)
+    o, dx, dw, t_after = _run(kind, x, w, y, hy, t0=0.123, lamb=st.lamb)
+    np.testing.assert_allclose(o["logits"].cpu().numpy(), ref.logits, atol=LOGIT_TOL, rtol=0)
+    np.testing.assert_allclose(o["cos_s"].cpu().numpy(), ref.cos_s, atol=LOGIT_TOL, rtol=0)
+    assert abs(o["loss"].item() - ref.loss) < 1e-3
+    np.testing.assert_allclose(o["lse"].cpu().numpy(), ref.lse, atol=1e-3)
+    assert tuple(o["topk"].cpu().numpy()) == (ref.top1, ref.top5)
+    np.testing.assert_allclose(dx, ref.dx, atol=1e-3 * np.abs(ref.dx).max(), rtol=0)
+    np.testing.assert_allclose(dw, ref.dw, atol=1e-3 * np.abs(ref.dw).max(), rtol=0)
+    if kind == H.CURR:
+        assert t_after == pytest.approx(st.t, abs=1e-6)
+
+
 def test_pair_cosine_and_threshold(golden_dir):
     from frx import ops
     g = np.load(os.path.join(golden_dir, "verify_threshold.npz"))
