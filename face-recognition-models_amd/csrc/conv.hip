@@ -34,6 +34,7 @@ static int launch_igemm(hipStream_t st, ConvArgs a, int dtype) {
     a.tilesM = t;
   }
   a.tilesN = cdiv(a.Ncol, c.bn);
+  c.ns = dma_stages(c, !a.in_scale && !a.X2, a.mode == MODE_STEM);
   const int grid = (int)round_up(a.tilesM, 8) * a.tilesN;
   int epi = EPI_PLAIN;
   if (a.epi_bnbwd) epi = (a.e_out || a.e_bits) ? EPI_BNBWD_OUT : EPI_BNBWD;

@@ -123,6 +123,28 @@ template <int ESZ> struct Raw8 {
   }
 };
 
+// ---- LDS-DMA (buffer_load_dwordx4 ... lds): a tile row goes from global memory straight into LDS, no VGPR hop, no ds_write.
+// Semantics measured on gfx950 (scripts/probes/dma_probe.hip): the wave's 64 x 16 bytes land LANE-LINEAR at M0 + lane * 16;
+// an out-of-range lane (offset past the descriptor) writes ZEROS; the scalar offset moves the global side only; the
+// instruction's immediate offset moves BOTH sides (so it is not used).  hipcc knows nothing about what an asm statement
+// has in flight: the kernel counts its own vmcnt (s_waitcnt below) -- with the builtin form it would wait vmcnt(0)
+// before every ds_read that may alias the destination.
+__device__ __forceinline__ u32x4_t raw_rsrc(const void* p, unsigned bytes) {
+  const unsigned long long q = (unsigned long long)p;
+  u32x4_t r;
+  r[0] = (unsigned)q; r[1] = (unsigned)(q >> 32); r[2] = bytes; r[3] = 0x00020000u;
+  return r;
+}
+__device__ __forceinline__ void dma16(u32x4_t rsrc, unsigned lds_addr, unsigned voff, int soff) {
+  unsigned keep;      // M0 is the compiler's: save / restore it inside the one statement that uses it
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");
+}
+
 // ds_read_b128 of a [rows][64 B] image is 2-way bank-conflicted for the 16x16x32 fragment
 // pattern (row = lane&15, chunk = lane>>4); XOR-ing the 16-byte chunk index with h[(row>>2)&3],
 // h = {0,2,3,1}, makes every 16-lane service group hit 16 distinct slots.
@@ -247,7 +269,7 @@ static inline unsigned igemm_pro_lds(int pro, int Kc) { return pro ? (pro == 2 ?
 
 // MODE (gather geometry) and PRO (BN+ReLU prologue) are compile-time so the steady-state K loop is
 // straight-line code: hipcc then keeps counted s_waitcnt vmcnt(N) for the register ring.
-template <typename T, int BM, int BN, int WM, int WN, int MODE, int PRO, int EPI, bool ADD, int KC = 64, int PD = 3>   // PRO: 0 none, 1 BN+ReLU, 2 BN-backward affine; KC: bytes of the contraction axis per row and K-chunk; PD: ring depth
+template <typename T, int BM, int BN, int WM, int WN, int MODE, int PRO, int EPI, bool ADD, int KC = 64, int PD = 3, int NS = 0>   // PRO: 0 none, 1 BN+ReLU, 2 BN-backward affine; KC: bytes of the contraction axis per row and K-chunk; PD: ring depth; NS > 0: LDS-DMA staging into a ring of NS LDS stages (PRO == 0 only) instead of the register ring
 // waves per SIMD the register budget must allow: 3 where the kernel fits 168 registers without spilling (measured:
 // +10-20 % on the prologue-free variants), 2 for the BN-prologue variants (they spill 35-50 registers at 3)
 // (WM x WN = 4 waves; or 8 waves on a 128x128 tile for launches with too few tiles to give every SIMD two waves)
@@ -255,6 +277,8 @@ template <typename T, int BM, int BN, int WM, int WN, int MODE, int PRO, int EPI
 #define FRX_OCC4W 0
 #endif
 __global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN == 8 ? 4 : (FRX_OCC4W ? FRX_OCC4W : ((PRO == 0 && EPI != EPI_BNBWD_OUT && !ADD) ? 3 : 2)))) void k_igemm(ConvArgs a) {
+  constexpr bool DMA = NS > 0;
+  static_assert(!DMA || (PRO == 0 && MODE != MODE_STEM && NS >= 3 && NS <= 4), "LDS-DMA staging: prologue-free launches, 3 or 4 stages");
   constexpr int VEC = TT<T>::VEC, CE = KC / (int)sizeof(T);      // elements per 16-byte load; elements per K-chunk
   constexpr int CPR = KC / 16;                                   // 16-byte slots per row of the LDS image
   constexpr int NT = 64 * WM * WN, RPP = NT / CPR;     // threads; tile rows staged per pass (CPR x 16-byte loads per row)
@@ -264,7 +288,8 @@ __global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN 
   static_assert(KC == 64 || KC == 128, "K-chunk of 64 or 128 bytes");
   static_assert(MODE != MODE_STEM || KC == 64, "the stem's rows are 64 bytes per tap row");
   static_assert((WM * WN == 4 || WM * WN == 8) && WTM % 16 == 0 && WTN % 32 == 0 && ALD >= 1 && BLD >= 1, "bad wave tiling");
-  __shared__ __attribute__((aligned(16))) char smem[2 * STAGE];
+  __shared__ __attribute__((aligned(16))) char smem[(DMA ? NS : 2) * STAGE];
+  static_assert(!DMA || RPP % 16 == 0, "the source-side swizzle must be the same for every row a thread stages");
   // BN scale/shift of the input channels live in LDS: fetching them from global memory at commit
   // time would be the NEWEST vector-memory op and force vmcnt(0), draining the prefetch ring.
   // (dynamic LDS, igemm_pro_lds() bytes: sized by the layer's channel count -- a fixed 2048-channel table cost 24 KB,
@@ -295,6 +320,9 @@ __global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int chunk = tid & (CPR - 1), srow = tid / CPR;
+  // LDS-DMA writes lane-linear, so the XOR swizzle of the LDS image moves to the SOURCE side: the thread whose bytes land in
+  // slot `chunk` of its row fetches the logical chunk that belongs there (the same involution the fragment reads apply)
+  const int lchunk = DMA ? (chunk ^ swz_row<KC>(srow)) : chunk;
   const T* __restrict__ X = reinterpret_cast<const T*>(a.X);
   const T* __restrict__ Wp = reinterpret_cast<const T*>(a.W);
   const int Ktot = a.R * a.S * a.Kc;
@@ -345,7 +373,7 @@ __global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN 
 #pragma unroll
   for (int i = 0; i < BLD; ++i) {
     const int n = n0 + srow + RPP * i;                // rows past Ncol read zeros; their outputs are never stored
-    bvoff[i] = n < a.Ncol ? (unsigned)((n * ldw + chunk * VEC) * (int)sizeof(T)) : OOB;
+    bvoff[i] = n < a.Ncol ? (unsigned)((n * ldw + lchunk * VEC) * (int)sizeof(T)) : OOB;
   }
 
   if constexpr (PRO != 0) {
@@ -360,10 +388,11 @@ __global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN 
   int tr = tr0, ts = ts0, c0 = 0;   // current tap (r, s) and channel offset of the K-chunk
   // Register ring of PD K-chunks: HBM/L2 latency (~2k cycles under load) is several chunks of MFMA work,
   // so loads run PD-1 chunks ahead of the LDS write that consumes them.
-  uint4 ra[PD][ALD], rb[PD][BLD];
+  constexpr int RD = DMA ? 1 : PD;
+  uint4 ra[RD][ALD], rb[RD][BLD];
   uint4 ra2[PRO == 2 ? PD : 1][ALD];   // second gathered tensor (PRO == 2)
-  int rc0[PD];                  // channel offset each ring slot was loaded at (for the BN prologue)
-  unsigned rmask[PD];           // which of the slot's A rows were in bounds (padding stays exactly 0)
+  int rc0[RD];                  // channel offset each ring slot was loaded at (for the BN prologue)
+  unsigned rmask[RD];           // which of the slot's A rows were in bounds (padding stays exactly 0)
   unsigned avoff[ALD];          // byte offset of the gathered pixel of the CURRENT tap (OOB when out of bounds)
   bool aok[ALD];
 
@@ -391,7 +420,7 @@ __global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN 
         off = ((rn[i] * a.Hx + rh[i] + tr) * a.Wx + rw[i]) * 4;
       }
       aok[i] = ok;
-      avoff[i] = ok ? (unsigned)((off + chunk * VEC) * (int)sizeof(T)) : OOB;
+      avoff[i] = ok ? (unsigned)((off + lchunk * VEC) * (int)sizeof(T)) : OOB;
     }
   };
   set_tap();
@@ -418,6 +447,26 @@ __global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN 
     if (c0 >= span) {
       c0 = 0;
       if (MODE == MODE_STEM) { ++tr; } else { ts += tstep; if (ts >= a.S) { ts = ts0; tr += tstep; } }
+      if (kc + 1 < nk) set_tap();
+    }
+  };
+  // LDS-DMA form of issue + commit: chunk kc goes straight into LDS stage `stage` (wave w's 64 lanes fill 1 KiB = the
+  // 64 / CPR tile rows starting at row w * 64 / CPR + RPP * i, lane-linear); nothing waits here
+  const u32x4_t rawX = raw_rsrc(a.X, a.xbytes), rawW = raw_rsrc(a.W, a.wbytes);
+  const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
+  const unsigned wrow = (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;     // this wave's slice of every RPP-row pass
+  auto dma_chunk = [&](int kc, int stage) {
+    const int so = c0 * (int)sizeof(T);
+    const unsigned sa = lds0 + (unsigned)stage * STAGE + wrow, sb = sa + BM * KC;
+#pragma unroll
+    for (int i = 0; i < ALD; ++i) dma16(rawX, sa + i * RPP * KC, avoff[i], so);
+    const int sob = s2c ? ((tr * a.S + ts) * a.Kc + c0) * (int)sizeof(T) : kc * KC;
+#pragma unroll
+    for (int i = 0; i < BLD; ++i) dma16(rawW, sb + i * RPP * KC, bvoff[i], sob);
+    c0 += CE;
+    if (c0 >= a.Kc) {
+      c0 = 0;
+      ts += tstep; if (ts >= a.S) { ts = ts0; tr += tstep; }
       if (kc + 1 < nk) set_tap();
     }
   };
@@ -513,6 +562,33 @@ __global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN 
     if constexpr (PD > 3) { if (!GUARDED || k0 + 3 < nk) ring_step(k0 + 3, std::integral_constant<int, 3>{}, guarded_tag); }
   };
   static_assert(PD >= 2 && PD <= 4, "ring depth");
+  if constexpr (DMA) {
+    // chunk j lives in LDS stage j % NS; NS - 1 chunks are in flight.  One step: wait until this wave's part of chunk k
+    // has landed (counted: the younger chunks stay in flight across the barrier), barrier (every wave's part has landed,
+    // and every wave has finished reading the stage chunk k + NS - 1 is about to overwrite), issue, compute.
+    constexpr int LPC = ALD + BLD;                    // DMA instructions per thread and chunk
+#pragma unroll
+    for (int j = 0; j < NS - 1; ++j)
+      if (j < nk) dma_chunk(j, j);
+    FRX_STAMP(1);
+    int k = 0, stg = 0;
+    for (; k + NS - 1 < nk; ++k) {
+      wait_vmcnt<(NS - 2) * LPC>();
+      __builtin_amdgcn_s_barrier();
+      dma_chunk(k + NS - 1, stg == 0 ? NS - 1 : stg - 1);
+      compute_chunk(stg);
+      stg = stg + 1 == NS ? 0 : stg + 1;
+    }
+    for (; k < nk; ++k) {                             // tail: nothing left to issue, nk - 1 - k younger chunks in flight
+      const int younger = nk - 1 - k;
+      if (NS > 3 && younger >= 2) wait_vmcnt<2 * LPC>();
+      else if (younger >= 1) wait_vmcnt<LPC>();
+      else wait_vmcnt<0>();
+      __builtin_amdgcn_s_barrier();
+      compute_chunk(stg);
+      stg = stg + 1 == NS ? 0 : stg + 1;
+    }
+  } else {
   issue_chunk(0, std::integral_constant<int, 0>{});
   if constexpr (PD > 1) { if (1 < nk) issue_chunk(1, std::integral_constant<int, 1>{}); }
   if constexpr (PD > 2) { if (2 < nk) issue_chunk(2, std::integral_constant<int, 2>{}); }
@@ -523,6 +599,7 @@ __global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN 
   int kc = 0;
   for (; kc + 2 * PD - 1 < nk; kc += PD) ring_round(kc, std::false_type{});
   for (; kc < nk; kc += PD) ring_round(kc, std::true_type{});        // tail (and the whole loop when K is short)
+  }
 
   // ---- epilogue.  C/D map: col = lane&15 (pixel), row = (lane>>4)*4 + reg (channel slot).
   // Fragment pair (2a, 2a+1) holds, for this lane, channels 32a + 8*fq + [0..8) of pixel fr: 16-byte

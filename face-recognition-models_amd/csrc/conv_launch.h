@@ -7,7 +7,22 @@
 
 namespace frx {
 
-struct TileCfg { int bm, bn, waves, kc; };       // block tile (pixels x channels), waves per block, K-chunk bytes
+struct TileCfg { int bm, bn, waves, kc; int ns = 0; };       // block tile (pixels x channels), waves per block, K-chunk bytes; ns > 0: LDS-DMA staging, ns LDS stages
+
+// LDS-DMA staging (k_igemm<..., NS>) exists for the prologue-free launches on the two production tiles; FRX_IGEMM_DMA=0
+// switches it off, =3 / =4 picks the stage count of the 128x128 tile (tuning aid, read per launch)
+static inline int dma_stages(const TileCfg& c, bool prologue_free, bool stem) {
+  if (!prologue_free || stem) return 0;
+  const bool t128 = c.bm == 128 && c.bn == 128 && c.kc == 64, t64 = c.bm == 64 && c.bn == 128 && c.kc == 128;
+  if (!t128 && !t64) return 0;
+  int ns = t128 ? 4 : 3;
+  if (const char* e = getenv("FRX_IGEMM_DMA")) {
+    const int v = atoi(e);
+    if (v == 0) return 0;
+    if (t128 && (v == 3 || v == 4)) ns = v;
+  }
+  return ns;
+}
 
 // tuning aid: FRX_IGEMM_TILE = "BMxBNxWAVESxKC" out of the list FRX_IGEMM_LAUNCH instantiates
 static inline bool tile_from_env(TileCfg* c) {
@@ -15,7 +30,7 @@ static inline bool tile_from_env(TileCfg* c) {
   if (!e) return false;
   int bm, bn, w, kc;
   if (sscanf(e, "%dx%dx%dx%d", &bm, &bn, &w, &kc) != 4) return false;
-  *c = TileCfg{bm, bn, w, kc};
+  *c = TileCfg{bm, bn, w, kc, 0};
   return true;
 }
 
@@ -54,8 +69,9 @@ int launch_wgrad(hipStream_t st, const WgradArgs& a, int dtype, int bt, int wmod
 int launch_wgrad_grouped(hipStream_t st, int dtype, const WgradArgs* layers, const WgradItem* items, int nitems, bool small_tiles,
                          int* draw_counters);
 
-#define FRX_IGEMM_K(T_, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, ADD_, KC_) \
-  hipLaunchKernelGGL((k_igemm<T_, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, ADD_, KC_>), dim3(grid), dim3(64 * WM_ * WN_), igemm_pro_lds(PRO_, a.Kc), st, a)
+#define FRX_IGEMM_KN(T_, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, ADD_, KC_, NS_) \
+  hipLaunchKernelGGL((k_igemm<T_, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, ADD_, KC_, 3, NS_>), dim3(grid), dim3(64 * WM_ * WN_), igemm_pro_lds(PRO_, a.Kc), st, a)
+#define FRX_IGEMM_K(T_, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, ADD_, KC_) FRX_IGEMM_KN(T_, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, ADD_, KC_, 0)
 #define FRX_IGEMM_LAUNCH64(T_, MODE_, PRO_, EPI_, ADD_)                                                                    \
   do {                                                                                                                     \
     if (c.bm == 128 && c.bn == 128) FRX_IGEMM_K(T_, 128, 128, 2, 4, MODE_, PRO_, EPI_, ADD_, 64);                           \
@@ -71,6 +87,20 @@ int launch_wgrad_grouped(hipStream_t st, int dtype, const WgradArgs* layers, con
   do {                                                                          \
     if (dtype == FRX_BF16) FRX_IGEMM_LAUNCH(bf16_t, MODE_, PRO_, EPI_, ADD_);   \
     else FRX_IGEMM_LAUNCH(float, MODE_, PRO_, EPI_, ADD_);                      \
+  } while (0)
+
+// prologue-free launches: the LDS-DMA instantiations where c.ns says so
+#define FRX_IGEMM_LAUNCH_DMA(T_, MODE_, EPI_, ADD_)                                                                        \
+  do {                                                                                                                     \
+    if (c.ns == 4 && c.bm == 128 && c.bn == 128) FRX_IGEMM_KN(T_, 128, 128, 2, 4, MODE_, 0, EPI_, ADD_, 64, 4);            \
+    else if (c.ns == 3 && c.bm == 128 && c.bn == 128) FRX_IGEMM_KN(T_, 128, 128, 2, 4, MODE_, 0, EPI_, ADD_, 64, 3);       \
+    else if (c.ns == 3 && c.bm == 64 && c.bn == 128 && c.kc == 128) FRX_IGEMM_KN(T_, 64, 128, 1, 4, MODE_, 0, EPI_, ADD_, 128, 3); \
+    else FRX_IGEMM_LAUNCH(T_, MODE_, 0, EPI_, ADD_);                                                                       \
+  } while (0)
+#define FRX_IGEMM_DT_DMA(MODE_, EPI_, ADD_)                                     \
+  do {                                                                          \
+    if (dtype == FRX_BF16) FRX_IGEMM_LAUNCH_DMA(bf16_t, MODE_, EPI_, ADD_);     \
+    else FRX_IGEMM_LAUNCH_DMA(float, MODE_, EPI_, ADD_);                        \
   } while (0)
 
 // (the stem's rows are 64 bytes per tap row: 64-byte K-chunks only)

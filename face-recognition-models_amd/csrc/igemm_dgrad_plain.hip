@@ -3,13 +3,13 @@
 namespace frx {
 int launch_igemm_dgrad_plain(hipStream_t st, const ConvArgs& a, int dtype, TileCfg c, int grid, int epi, bool add) {
   if (add) {
-    if (epi == EPI_PLAIN) FRX_IGEMM_DT(MODE_DGRAD, 0, EPI_PLAIN, true);
-    else if (epi == EPI_BNBWD) FRX_IGEMM_DT(MODE_DGRAD, 0, EPI_BNBWD, true);
-    else FRX_IGEMM_DT(MODE_DGRAD, 0, EPI_BNBWD_OUT, true);
+    if (epi == EPI_PLAIN) FRX_IGEMM_DT_DMA(MODE_DGRAD, EPI_PLAIN, true);
+    else if (epi == EPI_BNBWD) FRX_IGEMM_DT_DMA(MODE_DGRAD, EPI_BNBWD, true);
+    else FRX_IGEMM_DT_DMA(MODE_DGRAD, EPI_BNBWD_OUT, true);
   } else {
-    if (epi == EPI_PLAIN) FRX_IGEMM_DT(MODE_DGRAD, 0, EPI_PLAIN, false);
-    else if (epi == EPI_BNBWD) FRX_IGEMM_DT(MODE_DGRAD, 0, EPI_BNBWD, false);
-    else FRX_IGEMM_DT(MODE_DGRAD, 0, EPI_BNBWD_OUT, false);
+    if (epi == EPI_PLAIN) FRX_IGEMM_DT_DMA(MODE_DGRAD, EPI_PLAIN, false);
+    else if (epi == EPI_BNBWD) FRX_IGEMM_DT_DMA(MODE_DGRAD, EPI_BNBWD, false);
+    else FRX_IGEMM_DT_DMA(MODE_DGRAD, EPI_BNBWD_OUT, false);
   }
   FRX_LAUNCH_CHECK();
   return FRX_OK;

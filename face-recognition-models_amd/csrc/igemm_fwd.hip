@@ -7,8 +7,8 @@ int launch_igemm_fwd(hipStream_t st, const ConvArgs& a, int dtype, TileCfg c, in
     else if (epi == EPI_PLAIN) FRX_IGEMM_DT(MODE_FWD, 1, EPI_PLAIN, false);
     else { set_error("igemm fwd: unsupported epilogue %d with a prologue", epi); return FRX_ERR_ARG; }
   } else {
-    if (epi == EPI_STATS) FRX_IGEMM_DT(MODE_FWD, 0, EPI_STATS, false);
-    else if (epi == EPI_PLAIN) FRX_IGEMM_DT(MODE_FWD, 0, EPI_PLAIN, false);
+    if (epi == EPI_STATS) FRX_IGEMM_DT_DMA(MODE_FWD, EPI_STATS, false);
+    else if (epi == EPI_PLAIN) FRX_IGEMM_DT_DMA(MODE_FWD, EPI_PLAIN, false);
     else if (epi == EPI_FC) FRX_IGEMM_DT(MODE_FWD, 0, EPI_FC, false);
     else { set_error("igemm fwd: unsupported epilogue %d", epi); return FRX_ERR_ARG; }
   }

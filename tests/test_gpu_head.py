@@ -88,7 +88,16 @@ def test_head_vs_oracle_seeded(name, shape):
     st = H.HeadState(iter=6, t=0.123)
     ref = H.head_forward_backward(kind, x, w, y, hy, st, dtype=np.float64)
     o, dx, dw, t_after = _run(kind, x, w, y, hy, t0=0.123, lamb=st.lamb)
-    np.testing.assert_allclose(o["logits"].cpu().numpy(), ref.logits, atol=LOGIT_TOL, rtol=0)
+    ok = np.ones(ref.logits.shape, dtype=bool)
+    if kind == H.CURR:
+        # CurricularFace's hard-example mask cos > cos(theta_y + m) (criterion.py:560-565) is a step: of 11 M cosines a
+        # handful sit within fp32 rounding of their row's threshold and take the other branch than float64 does (the
+        # reference's own fp32 run has the same freedom).  They are left out of the logit comparison, and counted.
+        ty = ref.cos_s[np.arange(N), y] / hy.s
+        ctm = ty * np.cos(hy.m) - np.sqrt(np.maximum(0.0, 1 - ty * ty)) * np.sin(hy.m)
+        ok = np.abs(ref.cos_s / hy.s - ctm[:, None]) > 3e-6
+        assert (~ok).sum() <= max(2, 1e-5 * ok.size)
+    np.testing.assert_allclose(o["logits"].cpu().numpy()[ok], ref.logits[ok], atol=LOGIT_TOL, rtol=0)
     np.testing.assert_allclose(o["cos_s"].cpu().numpy(), ref.cos_s, atol=LOGIT_TOL, rtol=0)
     assert abs(o["loss"].item() - ref.loss) < 1e-3
     np.testing.assert_allclose(o["lse"].cpu().numpy(), ref.lse, atol=1e-3)
@@ -161,7 +170,16 @@ def test_head_ragged_85742_vs_float64_oracle(name, N, Cc):
     st = H.HeadState(iter=6, t=0.123)
     ref = H.head_forward_backward(kind, x, w, y, hy, st, dtype=np.float64)
     o, dx, dw, t_after = _run(kind, x, w, y, hy, t0=0.123, lamb=st.lamb)
-    np.testing.assert_allclose(o["logits"].cpu().numpy(), ref.logits, atol=LOGIT_TOL, rtol=0)
+    ok = np.ones(ref.logits.shape, dtype=bool)
+    if kind == H.CURR:
+        # CurricularFace's hard-example mask cos > cos(theta_y + m) (criterion.py:560-565) is a step: of 11 M cosines a
+        # handful sit within fp32 rounding of their row's threshold and take the other branch than float64 does (the
+        # reference's own fp32 run has the same freedom).  They are left out of the logit comparison, and counted.
+        ty = ref.cos_s[np.arange(N), y] / hy.s
+        ctm = ty * np.cos(hy.m) - np.sqrt(np.maximum(0.0, 1 - ty * ty)) * np.sin(hy.m)
+        ok = np.abs(ref.cos_s / hy.s - ctm[:, None]) > 3e-6
+        assert (~ok).sum() <= max(2, 1e-5 * ok.size)
+    np.testing.assert_allclose(o["logits"].cpu().numpy()[ok], ref.logits[ok], atol=LOGIT_TOL, rtol=0)
     np.testing.assert_allclose(o["cos_s"].cpu().numpy(), ref.cos_s, atol=LOGIT_TOL, rtol=0)
     assert abs(o["loss"].item() - ref.loss) < 1e-3
     np.testing.assert_allclose(o["lse"].cpu().numpy(), ref.lse, atol=1e-3)
