@@ -507,6 +507,48 @@ __global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN 
     for (int j = 0; j < FN; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int fr = lane & 15, fq = lane >> 4;
+  // (LDS-DMA path) the two halves of compute_chunk, so that the fragment reads of chunk k + 1 can be in flight under the
+  // MFMAs of chunk k: two fragment sets, indexed at compile time only
+  constexpr int KS = KC / 64;
+  uint4 pfa[DMA ? 2 : 1][KS][FM], pfb[DMA ? 2 : 1][KS][FN];
+  auto read_frags = [&](int stage, auto par_tag) {
+    constexpr int P = decltype(par_tag)::value;
+    const char* As = smem + stage * STAGE;
+    const char* Bs = As + BM * KC;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int row = wn * WTN + chan_of(j, fr);
+        pfb[P][ks][j] = *reinterpret_cast<const uint4*>(Bs + (row * CPR + ((ks * 4 + fq) ^ swz_row<KC>(row))) * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i) {
+        const int row = wm * WTM + i * 16 + fr;
+        pfa[P][ks][i] = *reinterpret_cast<const uint4*>(As + (row * CPR + ((ks * 4 + fq) ^ swz_row<KC>(row))) * 16);
+      }
+    }
+  };
+  auto mfma_frags = [&](auto par_tag) {
+    constexpr int P = decltype(par_tag)::value;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int i = 0; i < FM; ++i)
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          if constexpr (sizeof(T) == 2) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&pfb[P][ks][j]),
+                                                                *reinterpret_cast<bf16x8*>(&pfa[P][ks][i]), acc[i][j], 0, 0, 0);
+          } else {
+            const float* pa = reinterpret_cast<const float*>(&pfa[P][ks][i]);
+            const float* pb = reinterpret_cast<const float*>(&pfb[P][ks][j]);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(pb[q], pa[q], acc[i][j], 0, 0, 0);
+          }
+        }
+  };
   auto compute_chunk = [&](int cur) {
     const char* As = smem + cur * STAGE;
     const char* Bs = As + BM * KC;
@@ -563,30 +605,50 @@ __global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN 
   };
   static_assert(PD >= 2 && PD <= 4, "ring depth");
   if constexpr (DMA) {
-    // chunk j lives in LDS stage j % NS; NS - 1 chunks are in flight.  One step: wait until this wave's part of chunk k
-    // has landed (counted: the younger chunks stay in flight across the barrier), barrier (every wave's part has landed,
-    // and every wave has finished reading the stage chunk k + NS - 1 is about to overwrite), issue, compute.
+    // Chunk j lives in LDS stage j % NS.  Software pipeline, one barrier per chunk:
+    //   step k:  wait until this wave's part of chunk k + 1 has landed (counted: the younger chunks stay in flight across
+    //            the barrier) | barrier: every wave's part of chunk k + 1 has landed, and every wave has consumed the
+    //            fragments of chunk k - 1 | issue chunk k + NS - 1 into the stage chunk k - 1 just left | read the fragments
+    //            of chunk k + 1 (they arrive under the MFMAs) | MFMAs of chunk k on the fragments read during step k - 1.
+    // The stage of chunk k itself sits idle during step k (its fragments are in registers): re-using it one step
+    // earlier would race the DMA against fragment reads another wave may still have in flight.
     constexpr int LPC = ALD + BLD;                    // DMA instructions per thread and chunk
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
 #pragma unroll
     for (int j = 0; j < NS - 1; ++j)
       if (j < nk) dma_chunk(j, j);
+    if (nk >= NS - 1) wait_vmcnt<(NS - 2) * LPC>(); else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    read_frags(0, P0{});
     FRX_STAMP(1);
-    int k = 0, stg = 0;
-    for (; k + NS - 1 < nk; ++k) {
-      wait_vmcnt<(NS - 2) * LPC>();
-      __builtin_amdgcn_s_barrier();
-      dma_chunk(k + NS - 1, stg == 0 ? NS - 1 : stg - 1);
-      compute_chunk(stg);
-      stg = stg + 1 == NS ? 0 : stg + 1;
+    int k = 0, stg = 0;                               // stg = k % NS
+    // (STEADY: no branch between the fragment reads and the MFMAs -- at a join hipcc would wait lgkmcnt(0), i.e. for the
+    // reads it has just issued, instead of only for the older set the MFMAs take)
+    auto pstep = [&](auto par_tag, auto steady_tag) {
+      constexpr int P = decltype(par_tag)::value;
+      constexpr bool STEADY = decltype(steady_tag)::value;
+      const int nxt = stg + 1 == NS ? 0 : stg + 1, prv = stg == 0 ? NS - 1 : stg - 1;
+      if (STEADY || k + 1 < nk) {
+        // issued so far: chunks 0 .. min(nk, k + NS - 1) - 1; chunk k + 1 must have landed
+        const int younger = (k + NS - 1 < nk ? k + NS - 1 : nk) - (k + 2);
+        if (NS > 3 && (STEADY || younger >= NS - 3)) wait_vmcnt<(NS - 3) * LPC>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (STEADY || k + NS - 1 < nk) dma_chunk(k + NS - 1, prv);
+        read_frags(nxt, std::integral_constant<int, 1 - P>{});
+      }
+      mfma_frags(par_tag);
+      stg = nxt;
+      ++k;
+    };
+    for (; k + NS < nk; ) {               // two steady steps: k + 1 + NS - 1 < nk
+      pstep(P0{}, std::true_type{});
+      pstep(P1{}, std::true_type{});
     }
-    for (; k < nk; ++k) {                             // tail: nothing left to issue, nk - 1 - k younger chunks in flight
-      const int younger = nk - 1 - k;
-      if (NS > 3 && younger >= 2) wait_vmcnt<2 * LPC>();
-      else if (younger >= 1) wait_vmcnt<LPC>();
-      else wait_vmcnt<0>();
-      __builtin_amdgcn_s_barrier();
-      compute_chunk(stg);
-      stg = stg + 1 == NS ? 0 : stg + 1;
+    while (k < nk) {
+      pstep(P0{}, std::false_type{});
+      if (k >= nk) break;
+      pstep(P1{}, std::false_type{});
     }
   } else {
   issue_chunk(0, std::integral_constant<int, 0>{});
