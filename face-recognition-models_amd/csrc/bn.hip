@@ -3,6 +3,7 @@
 // Reference call sites: nn.BatchNorm2d x53, nn.ReLU x49, residual add x16, MaxPool2d,
 // AdaptiveAvgPool2d of the torchvision ResNet-50 built in main_code/utils/backbones.py:16-18.
 #include "conv_kernels.h"
+#include <stdlib.h>
 
 namespace frx {
 
@@ -79,18 +80,15 @@ __global__ __launch_bounds__(FIN_THREADS) void k_bn_finalize(const float* __rest
   int c;
   partial_colsum(partial, rows, C, s, q, c);
   if (threadIdx.x >= 16 || c >= C) return;
-  const double mean = s / count;
-  double var = q / count - mean * mean;
-  if (var < 0.0) var = 0.0;
-  const float invstd = (float)(1.0 / sqrt(var + (double)eps));
-  const float sc = gamma[c] * invstd;
-  mean_o[c] = (float)mean;
+  float mean, invstd, sc, sh; double var;
+  bn_fwd_consts(s, q, 1.0 / count, gamma[c], beta[c], eps, mean, invstd, sc, sh, var);
+  mean_o[c] = mean;
   invstd_o[c] = invstd;
   scale_o[c] = sc;
-  shift_o[c] = beta[c] - (float)mean * sc;
+  shift_o[c] = sh;
   if (rmean) {
     const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
-    rmean[c] = (1.f - momentum) * rmean[c] + momentum * (float)mean;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
     rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
   }
 }
@@ -139,13 +137,39 @@ template <int V> __device__ __forceinline__ void fill_consts(float v, float (&o)
 // one 16-byte load pair per thread in flight leaves these sweeps latency-bound at ~2.6 TB/s.
 constexpr int RU = 4;
 
+// Per-channel constants derived from replicated totals (bn_tot.h) are staged in dynamic LDS, [table][C] floats
+extern __shared__ __attribute__((aligned(16))) float s_bn_dyn[];
+__device__ __forceinline__ void stage_fwd_consts(const BnTot& b, int C, float* lsc, float* lsh) {
+  bn_tot_foreach<256>(b.tot, b.R, C, [&](int c, double sm, double sq) {
+    float mean, invstd, sc, sh; double var;
+    bn_fwd_consts(sm, sq, b.inv_count, b.gamma[c], b.beta[c], b.eps, mean, invstd, sc, sh, var);
+    lsc[c] = sc; lsh[c] = sh;
+  });
+}
+__device__ __forceinline__ void stage_bwd_consts(const BnTot& b, int C, float* lcoef /* [3][C] */) {
+  bn_tot_foreach<256>(b.tot, b.R, C, [&](int c, double sa, double sb) {
+    float al, be, ga;
+    bn_bwd_consts(sa, sb, b.inv_count, b.gamma[c], b.mean[c], b.invstd[c], al, be, ga);
+    lcoef[c] = al; lcoef[C + c] = be; lcoef[2 * C + c] = ga;
+  });
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void k_merge_fwd(long rows, int C, const T* __restrict__ y3,
-                                                   const float* __restrict__ s3, const float* __restrict__ b3,
-                                                   const T* __restrict__ idn, const float* __restrict__ sd,
-                                                   const float* __restrict__ bd, T* __restrict__ out,
-                                                   uint8_t* __restrict__ mask) {
+                                                   const float* s3, const float* b3,
+                                                   const T* __restrict__ idn, const float* sd,
+                                                   const float* bd, T* __restrict__ out,
+                                                   uint8_t* __restrict__ mask, BnTot t3, BnTot td) {
   constexpr int V = Vec16<T>::N;
+  if (t3.tot) {               // (block-uniform) constants from the producers' totals instead of finalized arrays
+    stage_fwd_consts(t3, C, s_bn_dyn, s_bn_dyn + C);
+    s3 = s_bn_dyn; b3 = s_bn_dyn + C;
+    if (td.tot) {
+      stage_fwd_consts(td, C, s_bn_dyn + 2 * C, s_bn_dyn + 3 * C);
+      sd = s_bn_dyn + 2 * C; bd = s_bn_dyn + 3 * C;
+    }
+    __syncthreads();
+  }
   const RowWalk w(C, V);
   const long stride = (long)gridDim.x * w.rpp;
   for (int g0 = 0; g0 < w.groups; g0 += w.gpb) {
@@ -192,7 +216,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(long rows, int C, const T
                                                        const float* __restrict__ shift, int relu,
                                                        const float* __restrict__ mean,
                                                        const float* __restrict__ invstd, T* __restrict__ dz_out,
-                                                       float* __restrict__ partial, int g_pool_hw) {
+                                                       float* __restrict__ partial, int g_pool_hw, int tot_R) {
   constexpr int V = Vec16<T>::N;
   __shared__ float red[2][256][V + 1];
   // g_pool_hw > 0: `g` is the gradient of an average pool over g_pool_hw pixels, [rows / g_pool_hw][C]; each row takes
@@ -251,13 +275,31 @@ __global__ __launch_bounds__(256) void k_bn_bwd_reduce(long rows, int C, const T
 #pragma unroll
     for (int j = 0; j < V; ++j) { red[0][threadIdx.x][j] = s1[j]; red[1][threadIdx.x][j] = s2[j]; }
     __syncthreads();
+    float fa[V], fb[V];
     if (threadIdx.x < gpb) {
 #pragma unroll
       for (int j = 0; j < V; ++j) {
         float a = 0.f, b = 0.f;
         for (int rr = 0; rr < rpp; ++rr) { a += red[0][rr * gpb + threadIdx.x][j]; b += red[1][rr * gpb + threadIdx.x][j]; }
-        partial[((long)blockIdx.x * 2 + 0) * C + c + j] = a;
-        partial[((long)blockIdx.x * 2 + 1) * C + c + j] = b;
+        if (tot_R > 0) { fa[j] = a; fb[j] = b; }      // (added below, one contiguous 256-byte run per wave-instruction)
+        else {
+          partial[((long)blockIdx.x * 2 + 0) * C + c + j] = a;
+          partial[((long)blockIdx.x * 2 + 1) * C + c + j] = b;
+        }
+      }
+    }
+    if (tot_R > 0) {        // replicated totals (bn_tot.h): `partial` is [tot_R][2][C], ADDED to.  The sums go through LDS so
+      __syncthreads();      // that consecutive lanes add to consecutive channels (the shape float atomics run at full rate in)
+      float* flat = &red[0][0][0];                   // 2 * 256 * (V + 1) floats >= 2 * gpb * V
+      if (threadIdx.x < gpb) {
+#pragma unroll
+        for (int j = 0; j < V; ++j) { flat[threadIdx.x * V + j] = fa[j]; flat[gpb * V + threadIdx.x * V + j] = fb[j]; }
+      }
+      __syncthreads();
+      const int span = gpb * V;
+      for (int i = threadIdx.x; i < 2 * span; i += 256) {
+        const int which = i >= span ? 1 : 0, cc = i - which * span;
+        __hip_atomic_fetch_add(partial + ((long)(blockIdx.x % tot_R) * 2 + which) * C + g0 * V + cc, flat[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
     }
   }
@@ -277,12 +319,11 @@ __global__ __launch_bounds__(FIN_THREADS) void k_bn_bwd_finalize(const float* __
   if (dbeta) dbeta[c] += (float)a;
   if (dgamma) dgamma[c] += (float)b;
   // dy = k1*(dz - c1 - xhat*c2), xhat = (y-mu)*is   ==   alpha*dz + beta*y + gam   (affine in dz and y)
-  const double k1 = (double)gamma[c] * (double)invstd[c];
-  const double c1 = a / count, c2 = b / count;
-  const double is = (double)invstd[c], mu = (double)mean[c];
-  coef[c] = (float)k1;
-  coef[C + c] = (float)(-k1 * is * c2);
-  coef[2 * C + c] = (float)(k1 * (mu * is * c2 - c1));
+  float al, be, ga;
+  bn_bwd_consts(a, b, 1.0 / count, gamma[c], mean[c], invstd[c], al, be, ga);
+  coef[c] = al;
+  coef[C + c] = be;
+  coef[2 * C + c] = ga;
 }
 
 // dy = k1 * (dz - c1 - xhat*c2);  dz = g*mask with the same mask rule as the reduce kernel
@@ -293,8 +334,13 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(long rows, int C, const T*
                                                       const float* __restrict__ shift, int relu,
                                                       const float* __restrict__ mean,
                                                       const float* __restrict__ invstd,
-                                                      const float* __restrict__ coef, T* __restrict__ dy) {
+                                                      const float* coef, T* __restrict__ dy, BnTot bt) {
   constexpr int V = Vec16<T>::N;
+  if (bt.tot) {
+    stage_bwd_consts(bt, C, s_bn_dyn);
+    coef = s_bn_dyn;
+    __syncthreads();
+  }
   const RowWalk w(C, V);
   for (int g0 = 0; g0 < w.groups; g0 += w.gpb) {
     const int grp = g0 + w.tg, c = grp * V;
@@ -336,9 +382,14 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(long rows, int C, const T*
 // maximum in scan order (torch's tie rule) for the backward gather.
 template <typename T>
 __global__ __launch_bounds__(256) void k_pool_fwd(int N, int H, int W, int C, const T* __restrict__ y,
-                                                  const float* __restrict__ scale, const float* __restrict__ shift,
-                                                  T* __restrict__ out, uint8_t* __restrict__ argmax) {
+                                                  const float* scale, const float* shift,
+                                                  T* __restrict__ out, uint8_t* __restrict__ argmax, BnTot bt) {
   constexpr int V = Vec16<T>::N;
+  if (bt.tot) {
+    stage_fwd_consts(bt, C, s_bn_dyn, s_bn_dyn + C);
+    scale = s_bn_dyn; shift = s_bn_dyn + C;
+    __syncthreads();
+  }
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1, G = C / V;
   const long total = (long)N * Ho * Wo * G;
   // XCD-contiguous index ranges (block b runs on XCD b % 8): the overlapping 3x3 windows of neighbouring rows are
@@ -442,10 +493,17 @@ __global__ __launch_bounds__(256) void k_stem_bwd(int N, int H, int W, int C, co
                                                   const uint8_t* __restrict__ argmax, const T* __restrict__ y,
                                                   const float* __restrict__ scale, const float* __restrict__ shift,
                                                   const float* __restrict__ mean, const float* __restrict__ invstd,
-                                                  const float* __restrict__ coef, T* __restrict__ dy,
-                                                  float* __restrict__ partial) {
+                                                  const float* coef, T* __restrict__ dy,
+                                                  float* __restrict__ partial, BnTot bt, int tot_R) {
   constexpr int V = Vec16<T>::N;
   __shared__ float red[2][256][V + 1];
+  if constexpr (APPLY) {
+    if (bt.tot) {
+      stage_bwd_consts(bt, C, s_bn_dyn);
+      coef = s_bn_dyn;
+      __syncthreads();
+    }
+  }
   const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1, G = C / V;
   // One thread = one 2x2 pixel quad (rows 2a, 2a+1; columns 2b, 2b+1) of one channel group: the four windows (a..a+1,
   // b..b+1) that cover it are loaded ONCE and serve its four pixels (9 of the 16 pixel-window pairs are live), instead
@@ -525,8 +583,13 @@ __global__ __launch_bounds__(256) void k_stem_bwd(int N, int H, int W, int C, co
       for (int j = 0; j < V; ++j) {
         float a = 0.f, b = 0.f;
         for (int k = threadIdx.x; k < 256; k += G) { a += red[0][k][j]; b += red[1][k][j]; }
-        partial[((long)blockIdx.x * 2 + 0) * C + c + j] = a;
-        partial[((long)blockIdx.x * 2 + 1) * C + c + j] = b;
+        if (tot_R > 0) {
+          __hip_atomic_fetch_add(partial + ((long)(blockIdx.x % tot_R) * 2 + 0) * C + c + j, a, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_fetch_add(partial + ((long)(blockIdx.x % tot_R) * 2 + 1) * C + c + j, b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+          partial[((long)blockIdx.x * 2 + 0) * C + c + j] = a;
+          partial[((long)blockIdx.x * 2 + 1) * C + c + j] = b;
+        }
       }
     }
   }
@@ -564,6 +627,14 @@ static inline int row_grid(long rows, int C, int V) {
   if (b > 256 * 16) b = 256 * 16;
   if (b < 1) b = 1;
   return (int)b;
+}
+
+// Row sweeps whose blocks first derive their constants from replicated totals run fewer, longer-lived blocks: the
+// derivation is paid per block (FRX_TOT_ROW_GRID: tuning aid, read per launch)
+static inline int tot_row_grid(int grid) {
+  int cap = 1024;
+  if (const char* e = getenv("FRX_TOT_ROW_GRID")) cap = atoi(e) > 0 ? atoi(e) : cap;
+  return grid < cap ? grid : cap;
 }
 
 static inline int pool_grid(long work_items) {       // multiple of 8: the pool kernels split the index space per XCD
@@ -618,21 +689,33 @@ extern "C" int frx_bn_eval_affine(int device, frx_stream_t stream, int C, const 
   return FRX_OK;
 }
 
+static int check_bn_tot(const frx_bn_tot* t, bool forward, const char* who) {
+  FRX_CHECK_ARG(t->totals && t->gamma && (forward ? t->beta != nullptr : (t->mean && t->invstd)), "%s: frx_bn_tot has NULL pointers", who);
+  FRX_CHECK_ARG(frx_pow2(t->replicas) && t->count > 0.f, "%s: frx_bn_tot needs a power-of-two replica count and count > 0", who);
+  return FRX_OK;
+}
+
 static int merge_impl(int device, frx_stream_t stream, int dtype, int64_t rows, int C, const void* y3,
                       const float* s3, const float* b3, const void* idn, const float* sd,
-                      const float* bd, void* out, uint8_t* mask) {
+                      const float* bd, void* out, uint8_t* mask, const frx_bn_tot* t3 = nullptr, const frx_bn_tot* td = nullptr) {
   FRX_DT_CHECK(dtype);
-  FRX_CHECK_ARG(y3 && s3 && b3 && idn && out && rows > 0 && C % FRX_VEC(dtype) == 0, "block_merge_fwd: bad args");
+  FRX_CHECK_ARG(y3 && (t3 || (s3 && b3)) && idn && out && rows > 0 && C % FRX_VEC(dtype) == 0, "block_merge_fwd: bad args");
+  if (t3) { if (int rc = check_bn_tot(t3, true, "block_merge_fwd_tot")) return rc; }
+  if (td) { if (int rc = check_bn_tot(td, true, "block_merge_fwd_tot")) return rc; }
+  FRX_CHECK_ARG(!t3 || C <= 4096, "block_merge_fwd_tot: C=%d too wide for the LDS tables", C);
+  const unsigned dyn = t3 ? (unsigned)((td ? 4 : 2) * C * sizeof(float)) : 0u;
+  const BnTot a3 = bn_tot_arg(t3), ad = bn_tot_arg(td);
   FRX_CHECK_ARG(frx_groups_ok(C / FRX_VEC(dtype)), "block_merge_fwd: C=%d must give a power-of-two number of 16-byte groups", C);
   FRX_CHECK_ARG((sd == nullptr) == (bd == nullptr), "block_merge_fwd: sd/bd come together");
   FRX_ENTER(device);
-  const int grid = row_grid(rows, C, FRX_VEC(dtype));
+  int grid = row_grid(rows, C, FRX_VEC(dtype));
+  if (t3) grid = tot_row_grid(grid);
   if (dtype == FRX_BF16)
-    hipLaunchKernelGGL(k_merge_fwd<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (long)rows, C,
-                       (const bf16_t*)y3, s3, b3, (const bf16_t*)idn, sd, bd, (bf16_t*)out, mask);
+    hipLaunchKernelGGL(k_merge_fwd<bf16_t>, dim3(grid), dim3(256), dyn, (hipStream_t)stream, (long)rows, C,
+                       (const bf16_t*)y3, s3, b3, (const bf16_t*)idn, sd, bd, (bf16_t*)out, mask, a3, ad);
   else
-    hipLaunchKernelGGL(k_merge_fwd<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (long)rows, C,
-                       (const float*)y3, s3, b3, (const float*)idn, sd, bd, (float*)out, mask);
+    hipLaunchKernelGGL(k_merge_fwd<float>, dim3(grid), dim3(256), dyn, (hipStream_t)stream, (long)rows, C,
+                       (const float*)y3, s3, b3, (const float*)idn, sd, bd, (float*)out, mask, a3, ad);
   FRX_LAUNCH_CHECK();
   return FRX_OK;
 }
@@ -650,6 +733,12 @@ extern "C" int frx_block_merge_fwd_mask(int device, frx_stream_t stream, int dty
   return merge_impl(device, stream, dtype, rows, C, y3, s3, b3, idn, sd, bd, out, mask);
 }
 
+extern "C" int frx_block_merge_fwd_tot(int device, frx_stream_t stream, int dtype, int64_t rows, int C, const void* y3,
+                                       const frx_bn_tot* bn3, const void* idn, const frx_bn_tot* bnd, void* out, uint8_t* mask) {
+  FRX_CHECK_ARG(bn3 != nullptr, "block_merge_fwd_tot: bn3 is NULL");
+  return merge_impl(device, stream, dtype, rows, C, y3, nullptr, nullptr, idn, nullptr, nullptr, out, mask, bn3, bnd);
+}
+
 extern "C" int frx_bn_bwd_partial_rows(int64_t rows, int C) {
   // one partial row per block of k_bn_bwd_reduce; a block's threads each take RU rows per trip.  The dtype is
   // not known here: 8 channels per 16-byte group (bf16) gives the larger count, which fp32 callers over-allocate.
@@ -661,10 +750,11 @@ extern "C" int frx_bn_bwd_partial_rows(int64_t rows, int C) {
   return (int)b;
 }
 
-extern "C" int frx_bn_bwd_reduce(int device, frx_stream_t stream, int dtype, int64_t rows, int C, const void* g,
-                                 const void* y, const void* out, const float* scale, const float* shift, int relu,
-                                 const float* mean, const float* invstd, void* dz_out, float* partial, int g_pool_hw) {
+static int bwd_reduce_impl(int device, frx_stream_t stream, int dtype, int64_t rows, int C, const void* g,
+                           const void* y, const void* out, const float* scale, const float* shift, int relu,
+                           const float* mean, const float* invstd, void* dz_out, float* partial, int g_pool_hw, int tot_R) {
   FRX_DT_CHECK(dtype);
+  FRX_CHECK_ARG(tot_R == 0 || frx_pow2(tot_R), "bn_bwd_reduce_tot: replicas must be a power of two");
   FRX_CHECK_ARG(g && y && mean && invstd && partial && rows > 0, "bn_bwd_reduce: bad args");
   FRX_CHECK_ARG(g_pool_hw >= 0 && (g_pool_hw == 0 || rows % g_pool_hw == 0), "bn_bwd_reduce: rows=%ld is not a multiple of g_pool_hw=%d", (long)rows, g_pool_hw);
   const int V = FRX_VEC(dtype), groups = C / V;
@@ -676,13 +766,26 @@ extern "C" int frx_bn_bwd_reduce(int device, frx_stream_t stream, int dtype, int
   if (dtype == FRX_BF16)
     hipLaunchKernelGGL(k_bn_bwd_reduce<bf16_t>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (long)rows, C,
                        (const bf16_t*)g, (const bf16_t*)y, (const bf16_t*)out, scale, shift, relu, mean, invstd,
-                       (bf16_t*)dz_out, partial, g_pool_hw);
+                       (bf16_t*)dz_out, partial, g_pool_hw, tot_R);
   else
     hipLaunchKernelGGL(k_bn_bwd_reduce<float>, dim3(nblk), dim3(256), 0, (hipStream_t)stream, (long)rows, C,
                        (const float*)g, (const float*)y, (const float*)out, scale, shift, relu, mean, invstd,
-                       (float*)dz_out, partial, g_pool_hw);
+                       (float*)dz_out, partial, g_pool_hw, tot_R);
   FRX_LAUNCH_CHECK();
   return FRX_OK;
+}
+
+extern "C" int frx_bn_bwd_reduce(int device, frx_stream_t stream, int dtype, int64_t rows, int C, const void* g,
+                                 const void* y, const void* out, const float* scale, const float* shift, int relu,
+                                 const float* mean, const float* invstd, void* dz_out, float* partial, int g_pool_hw) {
+  return bwd_reduce_impl(device, stream, dtype, rows, C, g, y, out, scale, shift, relu, mean, invstd, dz_out, partial, g_pool_hw, 0);
+}
+extern "C" int frx_bn_bwd_reduce_tot(int device, frx_stream_t stream, int dtype, int64_t rows, int C, const void* g,
+                                     const void* y, const void* out, const float* scale, const float* shift, int relu,
+                                     const float* mean, const float* invstd, void* dz_out, float* totals, int replicas,
+                                     int g_pool_hw) {
+  FRX_CHECK_ARG(replicas > 0, "bn_bwd_reduce_tot: replicas must be positive");
+  return bwd_reduce_impl(device, stream, dtype, rows, C, g, y, out, scale, shift, relu, mean, invstd, dz_out, totals, g_pool_hw, replicas);
 }
 
 extern "C" int frx_bn_bwd_finalize(int device, frx_stream_t stream, const float* partial, int nblk, int C,
@@ -696,41 +799,71 @@ extern "C" int frx_bn_bwd_finalize(int device, frx_stream_t stream, const float*
   return FRX_OK;
 }
 
-extern "C" int frx_bn_bwd_apply(int device, frx_stream_t stream, int dtype, int64_t rows, int C, const void* g,
-                                const void* y, const void* out, const float* scale, const float* shift, int relu,
-                                const float* mean, const float* invstd, const float* coef, void* dy) {
+static int bwd_apply_impl(int device, frx_stream_t stream, int dtype, int64_t rows, int C, const void* g,
+                          const void* y, const void* out, const float* scale, const float* shift, int relu,
+                          const float* mean, const float* invstd, const float* coef, void* dy, const frx_bn_tot* bt) {
   FRX_DT_CHECK(dtype);
-  FRX_CHECK_ARG(g && y && mean && invstd && coef && dy && rows > 0 && C % FRX_VEC(dtype) == 0, "bn_bwd_apply: bad args");
+  FRX_CHECK_ARG(g && y && (bt || (mean && invstd && coef)) && dy && rows > 0 && C % FRX_VEC(dtype) == 0, "bn_bwd_apply: bad args");
+  if (bt) { if (int rc = check_bn_tot(bt, false, "bn_bwd_apply_tot")) return rc; }
+  FRX_CHECK_ARG(!bt || C <= 4096, "bn_bwd_apply_tot: C=%d too wide for the LDS tables", C);
+  const unsigned dyn = bt ? (unsigned)(3 * C * sizeof(float)) : 0u;
+  const BnTot ab = bn_tot_arg(bt);
   FRX_CHECK_ARG(frx_groups_ok(C / FRX_VEC(dtype)), "bn_bwd_apply: C=%d must give a power-of-two number of 16-byte groups", C);
   FRX_CHECK_ARG(out || !relu || (scale && shift), "bn_bwd_apply: ReLU mask needs out or scale/shift");
   FRX_ENTER(device);
-  const int grid = row_grid(rows, C, FRX_VEC(dtype));
+  int grid = row_grid(rows, C, FRX_VEC(dtype));
+  if (bt) grid = tot_row_grid(grid);
   if (dtype == FRX_BF16)
-    hipLaunchKernelGGL(k_bn_bwd_apply<bf16_t>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (long)rows, C,
+    hipLaunchKernelGGL(k_bn_bwd_apply<bf16_t>, dim3(grid), dim3(256), dyn, (hipStream_t)stream, (long)rows, C,
                        (const bf16_t*)g, (const bf16_t*)y, (const bf16_t*)out, scale, shift, relu, mean, invstd, coef,
-                       (bf16_t*)dy);
+                       (bf16_t*)dy, ab);
   else
-    hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (long)rows, C,
+    hipLaunchKernelGGL(k_bn_bwd_apply<float>, dim3(grid), dim3(256), dyn, (hipStream_t)stream, (long)rows, C,
                        (const float*)g, (const float*)y, (const float*)out, scale, shift, relu, mean, invstd, coef,
-                       (float*)dy);
+                       (float*)dy, ab);
+  FRX_LAUNCH_CHECK();
+  return FRX_OK;
+}
+
+extern "C" int frx_bn_bwd_apply(int device, frx_stream_t stream, int dtype, int64_t rows, int C, const void* g,
+                                const void* y, const void* out, const float* scale, const float* shift, int relu,
+                                const float* mean, const float* invstd, const float* coef, void* dy) {
+  return bwd_apply_impl(device, stream, dtype, rows, C, g, y, out, scale, shift, relu, mean, invstd, coef, dy, nullptr);
+}
+extern "C" int frx_bn_bwd_apply_tot(int device, frx_stream_t stream, int dtype, int64_t rows, int C, const void* g,
+                                    const void* y, const void* out, const float* scale, const float* shift, int relu,
+                                    const frx_bn_tot* bn, void* dy) {
+  FRX_CHECK_ARG(bn != nullptr, "bn_bwd_apply_tot: bn is NULL");
+  return bwd_apply_impl(device, stream, dtype, rows, C, g, y, out, scale, shift, relu, bn->mean, bn->invstd, nullptr, dy, bn);
+}
+
+static int pool_fwd_impl(int device, frx_stream_t stream, int dtype, int N, int H, int W, int C,
+                         const void* y, const float* scale, const float* shift, void* out, uint8_t* argmax, const frx_bn_tot* bt) {
+  FRX_DT_CHECK(dtype);
+  FRX_CHECK_ARG(y && (bt || (scale && shift)) && out && argmax && N > 0 && H > 1 && W > 1 && C > 0 && C % FRX_VEC(dtype) == 0, "stem_pool_fwd: bad args");
+  if (bt) { if (int rc = check_bn_tot(bt, true, "stem_pool_fwd_tot")) return rc; }
+  const unsigned dyn = bt ? (unsigned)(2 * C * sizeof(float)) : 0u;
+  const BnTot ab = bn_tot_arg(bt);
+  FRX_ENTER(device);
+  const long total = (long)N * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * C / FRX_VEC(dtype);
+  if (dtype == FRX_BF16)
+    hipLaunchKernelGGL(k_pool_fwd<bf16_t>, dim3(pool_grid(total)), dim3(256), dyn, (hipStream_t)stream, N, H, W, C,
+                       (const bf16_t*)y, scale, shift, (bf16_t*)out, argmax, ab);
+  else
+    hipLaunchKernelGGL(k_pool_fwd<float>, dim3(pool_grid(total)), dim3(256), dyn, (hipStream_t)stream, N, H, W, C,
+                       (const float*)y, scale, shift, (float*)out, argmax, ab);
   FRX_LAUNCH_CHECK();
   return FRX_OK;
 }
 
 extern "C" int frx_stem_pool_fwd(int device, frx_stream_t stream, int dtype, int N, int H, int W, int C,
                                  const void* y, const float* scale, const float* shift, void* out, uint8_t* argmax) {
-  FRX_DT_CHECK(dtype);
-  FRX_CHECK_ARG(y && scale && shift && out && argmax && N > 0 && H > 1 && W > 1 && C > 0 && C % FRX_VEC(dtype) == 0, "stem_pool_fwd: bad args");
-  FRX_ENTER(device);
-  const long total = (long)N * ((H - 1) / 2 + 1) * ((W - 1) / 2 + 1) * C / FRX_VEC(dtype);
-  if (dtype == FRX_BF16)
-    hipLaunchKernelGGL(k_pool_fwd<bf16_t>, dim3(pool_grid(total)), dim3(256), 0, (hipStream_t)stream, N, H, W, C,
-                       (const bf16_t*)y, scale, shift, (bf16_t*)out, argmax);
-  else
-    hipLaunchKernelGGL(k_pool_fwd<float>, dim3(pool_grid(total)), dim3(256), 0, (hipStream_t)stream, N, H, W, C,
-                       (const float*)y, scale, shift, (float*)out, argmax);
-  FRX_LAUNCH_CHECK();
-  return FRX_OK;
+  return pool_fwd_impl(device, stream, dtype, N, H, W, C, y, scale, shift, out, argmax, nullptr);
+}
+extern "C" int frx_stem_pool_fwd_tot(int device, frx_stream_t stream, int dtype, int N, int H, int W, int C,
+                                     const void* y, const frx_bn_tot* bn, void* out, uint8_t* argmax) {
+  FRX_CHECK_ARG(bn != nullptr, "stem_pool_fwd_tot: bn is NULL");
+  return pool_fwd_impl(device, stream, dtype, N, H, W, C, y, nullptr, nullptr, out, argmax, bn);
 }
 
 extern "C" int frx_stem_pool_bwd(int device, frx_stream_t stream, int dtype, int N, int H, int W, int C,
@@ -756,8 +889,12 @@ extern "C" int frx_stem_bwd_partial_rows(void) { return 1024; }
 
 static int stem_bwd_impl(int device, frx_stream_t stream, int dtype, int N, int H, int W, int C, const void* dout,
                          const uint8_t* argmax, const void* y, const float* scale, const float* shift, const float* mean,
-                         const float* invstd, const float* coef, void* dy, float* partial) {
+                         const float* invstd, const float* coef, void* dy, float* partial, const frx_bn_tot* bt = nullptr, int tot_R = 0) {
   FRX_DT_CHECK(dtype);
+  if (bt) { if (int rc = check_bn_tot(bt, false, "stem_bwd_apply_tot")) return rc; }
+  FRX_CHECK_ARG(tot_R == 0 || frx_pow2(tot_R), "stem_bwd_reduce_tot: replicas must be a power of two");
+  const unsigned dyn = bt ? (unsigned)(3 * C * sizeof(float)) : 0u;
+  const BnTot ab = bn_tot_arg(bt);
   FRX_CHECK_ARG(dout && argmax && y && scale && shift && N > 0 && H > 1 && W > 1 && C > 0 && C % FRX_VEC(dtype) == 0, "stem_bwd: bad args");
   const int G = C / FRX_VEC(dtype);
   FRX_CHECK_ARG(G <= 256 && 256 % G == 0, "stem_bwd: C=%d must give a power-of-two number (<= 256) of 16-byte groups", C);
@@ -766,11 +903,11 @@ static int stem_bwd_impl(int device, frx_stream_t stream, int dtype, int N, int 
   const dim3 grid(dy ? pool_grid((long)N * ((H + 1) / 2) * ((W + 1) / 2) * G) : frx_stem_bwd_partial_rows()), blk(256);      // (both multiples of 8)
   const hipStream_t st = (hipStream_t)stream;
   if (dy) {
-    if (dtype == FRX_BF16) hipLaunchKernelGGL((k_stem_bwd<bf16_t, true>), grid, blk, 0, st, N, H, W, C, (const bf16_t*)dout, argmax, (const bf16_t*)y, scale, shift, mean, invstd, coef, (bf16_t*)dy, partial);
-    else hipLaunchKernelGGL((k_stem_bwd<float, true>), grid, blk, 0, st, N, H, W, C, (const float*)dout, argmax, (const float*)y, scale, shift, mean, invstd, coef, (float*)dy, partial);
+    if (dtype == FRX_BF16) hipLaunchKernelGGL((k_stem_bwd<bf16_t, true>), grid, blk, dyn, st, N, H, W, C, (const bf16_t*)dout, argmax, (const bf16_t*)y, scale, shift, mean, invstd, coef, (bf16_t*)dy, partial, ab, tot_R);
+    else hipLaunchKernelGGL((k_stem_bwd<float, true>), grid, blk, dyn, st, N, H, W, C, (const float*)dout, argmax, (const float*)y, scale, shift, mean, invstd, coef, (float*)dy, partial, ab, tot_R);
   } else {
-    if (dtype == FRX_BF16) hipLaunchKernelGGL((k_stem_bwd<bf16_t, false>), grid, blk, 0, st, N, H, W, C, (const bf16_t*)dout, argmax, (const bf16_t*)y, scale, shift, mean, invstd, coef, (bf16_t*)dy, partial);
-    else hipLaunchKernelGGL((k_stem_bwd<float, false>), grid, blk, 0, st, N, H, W, C, (const float*)dout, argmax, (const float*)y, scale, shift, mean, invstd, coef, (float*)dy, partial);
+    if (dtype == FRX_BF16) hipLaunchKernelGGL((k_stem_bwd<bf16_t, false>), grid, blk, dyn, st, N, H, W, C, (const bf16_t*)dout, argmax, (const bf16_t*)y, scale, shift, mean, invstd, coef, (bf16_t*)dy, partial, ab, tot_R);
+    else hipLaunchKernelGGL((k_stem_bwd<float, false>), grid, blk, dyn, st, N, H, W, C, (const float*)dout, argmax, (const float*)y, scale, shift, mean, invstd, coef, (float*)dy, partial, ab, tot_R);
   }
   FRX_LAUNCH_CHECK();
   return FRX_OK;
@@ -788,6 +925,87 @@ extern "C" int frx_stem_bwd_apply(int device, frx_stream_t stream, int dtype, in
                                   const float* coef, void* dy) {
   FRX_CHECK_ARG(coef && dy, "stem_bwd_apply: NULL pointer");
   return stem_bwd_impl(device, stream, dtype, N, H, W, C, dout, argmax, y, scale, shift, nullptr, nullptr, coef, dy, nullptr);
+}
+
+extern "C" int frx_stem_bwd_reduce_tot(int device, frx_stream_t stream, int dtype, int N, int H, int W, int C, const void* dout,
+                                       const uint8_t* argmax, const void* y, const float* scale, const float* shift,
+                                       const float* mean, const float* invstd, float* totals, int replicas) {
+  FRX_CHECK_ARG(mean && invstd && totals && replicas > 0, "stem_bwd_reduce_tot: bad args");
+  return stem_bwd_impl(device, stream, dtype, N, H, W, C, dout, argmax, y, scale, shift, mean, invstd, nullptr, nullptr, totals, nullptr, replicas);
+}
+
+extern "C" int frx_stem_bwd_apply_tot(int device, frx_stream_t stream, int dtype, int N, int H, int W, int C, const void* dout,
+                                      const uint8_t* argmax, const void* y, const float* scale, const float* shift,
+                                      const frx_bn_tot* bn, void* dy) {
+  FRX_CHECK_ARG(bn && dy, "stem_bwd_apply_tot: NULL pointer");
+  return stem_bwd_impl(device, stream, dtype, N, H, W, C, dout, argmax, y, scale, shift, nullptr, nullptr, nullptr, dy, nullptr, bn, 0);
+}
+
+// ---- the batched closing launches of bn_tot.h: one thread per channel of every listed BatchNorm layer
+// forward row  [16] int64: {totals, replicas, C, count, gamma, beta, running_mean | 0, running_var | 0, mean, invstd, scale,
+//                           shift, first block, eps (float bits), momentum (float bits), 0}
+// backward row [16] int64: {totals, replicas, C, count, gamma, mean, invstd, dgamma | 0, dbeta | 0, coef, 0, 0, first block, 0, 0, 0}
+namespace frx {
+__device__ __forceinline__ const int64_t* batched_row(const int64_t* __restrict__ table, int n) {
+  int lo = 0, hi = n - 1;                 // last row whose first block is <= blockIdx.x
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (table[mid * 16 + 12] <= (int64_t)blockIdx.x) lo = mid; else hi = mid - 1;
+  }
+  return table + lo * 16;
+}
+__global__ __launch_bounds__(256) void k_bn_finalize_batched(const int64_t* __restrict__ table, int n) {
+  const int64_t* row = batched_row(table, n);
+  float* tot = (float*)row[0];
+  const int R = (int)row[1], C = (int)row[2];
+  const int c = ((int)blockIdx.x - (int)row[12]) * 256 + threadIdx.x;
+  if (c >= C) return;
+  const double count = (double)row[3];
+  double s, q;
+  bn_tot_sum(tot, R, C, c, s, q);
+  float mean, invstd, sc, sh; double var;
+  bn_fwd_consts(s, q, 1.0 / count, ((const float*)row[4])[c], ((const float*)row[5])[c], __int_as_float((int)row[13]), mean, invstd, sc, sh, var);
+  ((float*)row[8])[c] = mean; ((float*)row[9])[c] = invstd; ((float*)row[10])[c] = sc; ((float*)row[11])[c] = sh;
+  if (row[6]) {
+    const float momentum = __int_as_float((int)row[14]);
+    float* rmean = (float*)row[6]; float* rvar = (float*)row[7];
+    const double unb = count > 1.0 ? var * count / (count - 1.0) : var;
+    rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
+    rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
+  }
+  for (int r = 0; r < 2 * R; ++r) tot[r * C + c] = 0.f;          // ready for the next step's adds
+}
+__global__ __launch_bounds__(256) void k_bn_bwd_finalize_batched(const int64_t* __restrict__ table, int n) {
+  const int64_t* row = batched_row(table, n);
+  float* tot = (float*)row[0];
+  const int R = (int)row[1], C = (int)row[2];
+  const int c = ((int)blockIdx.x - (int)row[12]) * 256 + threadIdx.x;
+  if (c >= C) return;
+  double a, b;
+  bn_tot_sum(tot, R, C, c, a, b);
+  if (row[8]) ((float*)row[8])[c] += (float)a;            // dbeta
+  if (row[7]) ((float*)row[7])[c] += (float)b;            // dgamma
+  float al, be, ga;
+  bn_bwd_consts(a, b, 1.0 / (double)row[3], ((const float*)row[4])[c], ((const float*)row[5])[c], ((const float*)row[6])[c], al, be, ga);
+  float* coef = (float*)row[9];
+  coef[c] = al; coef[C + c] = be; coef[2 * C + c] = ga;
+  for (int r = 0; r < 2 * R; ++r) tot[r * C + c] = 0.f;
+}
+}  // namespace frx
+
+extern "C" int frx_bn_finalize_batched(int device, frx_stream_t stream, int n, const int64_t* table_dev, int total_blocks) {
+  FRX_CHECK_ARG(n > 0 && table_dev && total_blocks > 0, "bn_finalize_batched: bad args");
+  FRX_ENTER(device);
+  hipLaunchKernelGGL(k_bn_finalize_batched, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, table_dev, n);
+  FRX_LAUNCH_CHECK();
+  return FRX_OK;
+}
+extern "C" int frx_bn_bwd_finalize_batched(int device, frx_stream_t stream, int n, const int64_t* table_dev, int total_blocks) {
+  FRX_CHECK_ARG(n > 0 && table_dev && total_blocks > 0, "bn_bwd_finalize_batched: bad args");
+  FRX_ENTER(device);
+  hipLaunchKernelGGL(k_bn_bwd_finalize_batched, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, table_dev, n);
+  FRX_LAUNCH_CHECK();
+  return FRX_OK;
 }
 
 extern "C" int frx_avgpool_fwd(int device, frx_stream_t stream, int dtype, int N, int HW, int C, const void* x, void* out) {

@@ -34,18 +34,19 @@ static int launch_igemm(hipStream_t st, ConvArgs a, int dtype) {
     a.tilesM = t;
   }
   a.tilesN = cdiv(a.Ncol, c.bn);
-  c.ns = dma_stages(c, !a.in_scale && !a.X2, a.mode == MODE_STEM);
+  const bool has_pro = a.in_scale || a.in_tot.tot || a.X2;
+  c.ns = dma_stages(c, !has_pro, a.mode == MODE_STEM);
   const int grid = (int)round_up(a.tilesM, 8) * a.tilesN;
   int epi = EPI_PLAIN;
   if (a.epi_bnbwd) epi = (a.e_out || a.e_bits) ? EPI_BNBWD_OUT : EPI_BNBWD;
-  else if (a.stat_partial) epi = EPI_STATS;
+  else if (a.stat_partial || a.stat_tot) epi = EPI_STATS;
   else if (a.out_f32 || a.bias) epi = EPI_FC;
   if (a.mode == MODE_STEM) return launch_igemm_stem(st, a, dtype, c, grid, epi);
   if (a.mode == MODE_DGRAD)
     return a.X2 ? launch_igemm_dgrad_bn(st, a, dtype, c, grid, epi, a.addend != nullptr)
                 : launch_igemm_dgrad_plain(st, a, dtype, c, grid, epi, a.addend != nullptr);
   FRX_CHECK_ARG(a.addend == nullptr, "igemm fwd: addend is a dgrad feature");
-  return launch_igemm_fwd(st, a, dtype, c, grid, a.in_scale ? 1 : 0, epi);
+  return launch_igemm_fwd(st, a, dtype, c, grid, (a.in_scale || a.in_tot.tot) ? 1 : 0, epi);
 }
 
 static int check_conv(const frx_conv_desc* d) {
@@ -107,10 +108,18 @@ extern "C" int frx_stem_padded_dims(int Hi, int Wi, int* Hp, int* Wp) {
   return FRX_OK;
 }
 
-extern "C" int frx_conv_fwd(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x,
-                            const void* w, const float* in_scale, const float* in_shift, int in_relu,
-                            const float* bias, void* y, int out_f32, float* stat_partial) {
+static int conv_fwd_impl(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x,
+                         const void* w, const float* in_scale, const float* in_shift, int in_relu,
+                         const float* bias, void* y, int out_f32, float* stat_partial, const frx_bn_tot* in_bn,
+                         float* stat_totals, int stat_replicas) {
   if (int rc = check_conv(d)) return rc;
+  if (in_bn) {
+    FRX_CHECK_ARG(!d->stem, "conv_fwd_tot: the stem takes the raw image (no prologue)");
+    FRX_CHECK_ARG(in_bn->totals && in_bn->gamma && in_bn->beta && frx_pow2(in_bn->replicas) && in_bn->count > 0.f,
+                  "conv_fwd_tot: in_bn needs totals / gamma / beta, a power-of-two replica count and count > 0");
+    FRX_CHECK_ARG(d->Ci <= 2048, "conv_fwd_tot: BN prologue supports up to 2048 input channels (got %d)", d->Ci);
+  }
+  FRX_CHECK_ARG(!stat_totals || frx_pow2(stat_replicas), "conv_fwd_tot: stat_replicas must be a power of two");
   FRX_CHECK_ARG(x && w && y, "conv_fwd: NULL pointer");
   FRX_CHECK_ARG(!(d->stem && in_scale), "conv_fwd: the stem takes the raw image (no prologue)");
   FRX_CHECK_ARG((in_scale == nullptr) == (in_shift == nullptr), "conv_fwd: in_scale/in_shift must come together");
@@ -122,6 +131,7 @@ extern "C" int frx_conv_fwd(int device, frx_stream_t stream, const frx_conv_desc
   a.X = x; a.W = w; a.Y = y;
   a.in_scale = in_scale; a.in_shift = in_shift; a.in_relu = in_relu;
   a.bias = bias; a.stat_partial = stat_partial; a.out_f32 = out_f32;
+  a.in_tot = bn_tot_arg(in_bn); a.stat_tot = stat_totals; a.stat_R = stat_replicas;
   a.N = d->N; a.Ho = d->Ho; a.Wo = d->Wo; a.Ncol = d->Co; a.R = d->R; a.S = d->S;
   a.stride = d->stride; a.pad = d->pad;
   a.M = d->N * d->Ho * d->Wo;
@@ -133,6 +143,17 @@ extern "C" int frx_conv_fwd(int device, frx_stream_t stream, const frx_conv_desc
     a.mode = MODE_FWD; a.Hx = d->Hi; a.Wx = d->Wi; a.Kc = d->Ci;
   }
   return launch_igemm((hipStream_t)stream, a, d->dtype);
+}
+
+extern "C" int frx_conv_fwd(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x,
+                            const void* w, const float* in_scale, const float* in_shift, int in_relu,
+                            const float* bias, void* y, int out_f32, float* stat_partial) {
+  return conv_fwd_impl(device, stream, d, x, w, in_scale, in_shift, in_relu, bias, y, out_f32, stat_partial, nullptr, nullptr, 0);
+}
+
+extern "C" int frx_conv_fwd_tot(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x, const void* w,
+                                const frx_bn_tot* in_bn, int in_relu, void* y, float* stat_totals, int stat_replicas) {
+  return conv_fwd_impl(device, stream, d, x, w, nullptr, nullptr, in_relu, nullptr, y, 0, nullptr, in_bn, stat_totals, stat_replicas);
 }
 
 static int dgrad_impl(int device, frx_stream_t stream, const frx_conv_desc* d, const void* dy, const void* w_crsk,
@@ -150,9 +171,16 @@ static int dgrad_impl(int device, frx_stream_t stream, const frx_conv_desc* d, c
   a.s2c = (d->stride == 2 && (d->R > 1 || d->S > 1) && !getenv("FRX_DGRAD_NO_S2C")) ? 1 : 0;
   if (f) {
     if (f->pro_y) {
-      FRX_CHECK_ARG(f->pro_coef != nullptr, "conv_dgrad_bn: pro_y needs pro_coef");
+      FRX_CHECK_ARG((f->pro_coef != nullptr) != (f->pro_tot != nullptr), "conv_dgrad_bn: pro_y needs pro_coef or pro_tot (one of them)");
       FRX_CHECK_ARG(d->Co <= 2048, "conv_dgrad_bn: BN prologue supports up to 2048 channels (got %d)", d->Co);
-      a.X2 = f->pro_y; a.in_scale = f->pro_coef; a.in_shift = f->pro_coef + d->Co; a.pro_gam = f->pro_coef + 2 * d->Co;
+      a.X2 = f->pro_y;
+      if (f->pro_coef) { a.in_scale = f->pro_coef; a.in_shift = f->pro_coef + d->Co; a.pro_gam = f->pro_coef + 2 * d->Co; }
+      else {
+        const frx_bn_tot* t = f->pro_tot;
+        FRX_CHECK_ARG(t->totals && t->gamma && t->mean && t->invstd && frx_pow2(t->replicas) && t->count > 0.f,
+                      "conv_dgrad_bn: pro_tot needs totals / gamma / mean / invstd, a power-of-two replica count and count > 0");
+        a.pro_tot = bn_tot_arg(t);
+      }
     }
     if (f->addend_stride == 2) {
       FRX_CHECK_ARG(addend != nullptr, "conv_dgrad_bn: addend_stride without addend");
@@ -166,11 +194,14 @@ static int dgrad_impl(int device, frx_stream_t stream, const frx_conv_desc* d, c
       a.dy_out = f->pro_dy_out;
     }
     if (f->epi_y) {
-      FRX_CHECK_ARG(f->epi_mean && f->epi_invstd && f->epi_partial, "conv_dgrad_bn: epilogue needs mean / invstd / partial");
+      FRX_CHECK_ARG(f->epi_mean && f->epi_invstd && ((f->epi_partial != nullptr) != (f->epi_totals != nullptr)),
+                    "conv_dgrad_bn: epilogue needs mean / invstd and ONE of partial / totals");
+      FRX_CHECK_ARG(!f->epi_totals || frx_pow2(f->epi_replicas), "conv_dgrad_bn: epi_replicas must be a power of two");
       FRX_CHECK_ARG(f->epi_out || f->epi_out_bits || (f->epi_scale && f->epi_shift), "conv_dgrad_bn: epilogue mask needs epi_out(_bits) or scale/shift");
       a.epi_bnbwd = 1; a.e_y = f->epi_y; a.e_out = f->epi_out; a.e_scale = f->epi_scale; a.e_shift = f->epi_shift;
       a.e_bits = (const unsigned char*)f->epi_out_bits;
       a.e_mean = f->epi_mean; a.e_invstd = f->epi_invstd; a.stat_partial = f->epi_partial;
+      a.stat_tot = f->epi_totals; a.stat_R = f->epi_replicas;
     }
   }
   FRX_ENTER(device);

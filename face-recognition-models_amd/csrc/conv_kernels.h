@@ -14,6 +14,7 @@
 //         k order inside a chunk is permuted identically for A and B, which a sum allows)
 #pragma once
 #include "frx_common.h"
+#include "bn_tot.h"
 #include <type_traits>
 
 namespace frx {
@@ -56,6 +57,10 @@ struct ConvArgs {
   int add_stride;         // 2: addend is the COMPACT [N,ceil(Ho/2),ceil(Wo/2),Ncol] gradient of a stride-2 1x1 branch,
                           //    added at the even pixels only (the other 3/4 of that gradient are zeros nobody stores)
   float* stat_partial;    // optional [tilesM][2][Ncol]: column sums / sums of squares of Y
+  float* stat_tot;        // instead of stat_partial: replicated totals [stat_R][2][Ncol], ADDED to with float atomics (bn_tot.h)
+  int stat_R;
+  BnTot in_tot;           // PRO == 1 with in_scale == nullptr: the prologue's scale / shift are derived from these totals
+  BnTot pro_tot;          // PRO == 2 with in_scale == nullptr: alpha / beta / gam are derived from these totals
   int out_f32;            // store Y as fp32 regardless of T
   // PRO == 2 (dgrad): the gathered operand is the BN backward  alpha*dz + beta*y + gam  of two tensors
   const void* X2;         //   y (raw conv output), same indexing as X (= dz); in_scale = alpha, in_shift = beta
@@ -376,15 +381,37 @@ __global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN 
     bvoff[i] = n < a.Ncol ? (unsigned)((n * ldw + lchunk * VEC) * (int)sizeof(T)) : OOB;
   }
 
+  // The prologue's per-channel tables (dynamic LDS).  Filled AFTER the first K-chunks' global loads have been issued: the
+  // table's own loads (and, with replicated totals, the R rows per channel and the closing arithmetic) then run under the
+  // latency of the tile loads instead of in front of them.
+  auto fill_pro_tables = [&]() {
   if constexpr (PRO != 0) {
-    for (int c = tid; c < a.Kc; c += NT) {
-      float* t = s_pro + (c / VEC) * (NTAB * VEC) + (c % VEC);
-      t[0] = a.in_scale[c]; t[VEC] = a.in_shift[c];
-      if constexpr (PRO == 2) t[2 * VEC] = a.pro_gam[c];
+      if (a.in_scale) {
+        for (int c = tid; c < a.Kc; c += NT) {
+          float* t = s_pro + (c / VEC) * (NTAB * VEC) + (c % VEC);
+          t[0] = a.in_scale[c]; t[VEC] = a.in_shift[c];
+          if constexpr (PRO == 2) t[2 * VEC] = a.pro_gam[c];
+        }
+      } else if constexpr (PRO == 1) {      // the producer's replicated totals -> scale / shift (bn_tot.h)
+        const BnTot b = a.in_tot;
+        bn_tot_foreach<NT>(b.tot, b.R, a.Kc, [&](int c, double sm, double sq) {
+          float mean, invstd, sc, sh; double var;
+          bn_fwd_consts(sm, sq, b.inv_count, b.gamma[c], b.beta[c], b.eps, mean, invstd, sc, sh, var);
+          float* t = s_pro + (c / VEC) * (NTAB * VEC) + (c % VEC);
+          t[0] = sc; t[VEC] = sh;
+        });
+      } else {                              // (sum dz, sum dz * xhat) -> alpha / beta / gam
+        const BnTot b = a.pro_tot;
+        bn_tot_foreach<NT>(b.tot, b.R, a.Kc, [&](int c, double sa, double sb) {
+          float al, be, ga;
+          bn_bwd_consts(sa, sb, b.inv_count, b.gamma[c], b.mean[c], b.invstd[c], al, be, ga);
+          float* t = s_pro + (c / VEC) * (NTAB * VEC) + (c % VEC);
+          t[0] = al; t[VEC] = be; t[2 * VEC] = ga;
+        });
+      }
+      __syncthreads();
     }
-    __syncthreads();
-  }
-
+  };
   int tr = tr0, ts = ts0, c0 = 0;   // current tap (r, s) and channel offset of the K-chunk
   // Register ring of PD K-chunks: HBM/L2 latency (~2k cycles under load) is several chunks of MFMA work,
   // so loads run PD-1 chunks ahead of the LDS write that consumes them.
@@ -655,6 +682,7 @@ __global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN 
   if constexpr (PD > 1) { if (1 < nk) issue_chunk(1, std::integral_constant<int, 1>{}); }
   if constexpr (PD > 2) { if (2 < nk) issue_chunk(2, std::integral_constant<int, 2>{}); }
   if constexpr (PD > 3) { if (3 < nk) issue_chunk(3, std::integral_constant<int, 3>{}); }
+  fill_pro_tables();
   commit_chunk(0, std::integral_constant<int, 0>{});
   __syncthreads();
   FRX_STAMP(1);
@@ -844,7 +872,10 @@ __global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN 
       float sum = 0.f;
 #pragma unroll
       for (int w = 0; w < WM; ++w) sum += red[(which * WM + w) * BN + col];
-      a.stat_partial[((long)mt * 2 + which) * a.Ncol + n0 + col] = sum;
+      if (a.stat_tot)
+        __hip_atomic_fetch_add(a.stat_tot + ((long)(mt % a.stat_R) * 2 + which) * a.Ncol + n0 + col, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else
+        a.stat_partial[((long)mt * 2 + which) * a.Ncol + n0 + col] = sum;
     }
   }
 #ifdef FRX_DBG_TIMES

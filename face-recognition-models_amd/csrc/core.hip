@@ -17,12 +17,14 @@ extern "C" int frx_version(void) { return 100; /* 0.1.0 */ }
 extern "C" const char* frx_last_error(void) { return frx::g_err; }
 
 // sizeof() of the structs that cross the boundary, in declaration order: bindings check their own layouts against it
-extern "C" int frx_struct_sizes(int64_t sizes[4]) {
+extern "C" int frx_struct_sizes(int64_t sizes[8]) {
   FRX_CHECK_ARG(sizes != nullptr, "sizes is NULL");
   sizes[0] = (int64_t)sizeof(frx_head_desc);
   sizes[1] = (int64_t)sizeof(frx_conv_desc);
   sizes[2] = (int64_t)sizeof(frx_dgrad_fuse);
   sizes[3] = (int64_t)sizeof(frx_wgrad_job);
+  sizes[4] = (int64_t)sizeof(frx_bn_tot);
+  sizes[5] = sizes[6] = sizes[7] = 0;
   return FRX_OK;
 }
 

@@ -54,6 +54,7 @@ struct DeviceGuard {
 
 static inline size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 static inline int cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+static inline bool frx_pow2(int v) { return v > 0 && (v & (v - 1)) == 0; }
 
 // ---- device-side numeric helpers -------------------------------------------------
 typedef __bf16 bf16_t;

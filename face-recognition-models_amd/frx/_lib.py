@@ -25,10 +25,17 @@ class ConvDesc(C.Structure):
                                           "Ho", "Wo", "stem")]
 
 
+class BnTot(C.Structure):
+    """frx_bn_tot (include/frx.h): BatchNorm statistics as replicated totals"""
+    _fields_ = ([(n, C.c_void_p) for n in ("totals", "gamma", "beta", "mean", "invstd")]
+                + [("replicas", C.c_int32), ("count", C.c_float), ("eps", C.c_float), ("reserved", C.c_int32)])
+
+
 class DgradFuse(C.Structure):
     _fields_ = ([(n, C.c_void_p) for n in ("pro_y", "pro_coef", "epi_y", "epi_out", "epi_scale", "epi_shift",
                                            "epi_mean", "epi_invstd", "epi_partial", "epi_out_bits")]
-                + [("addend_stride", C.c_int32), ("pro_dy_out", C.c_void_p)])
+                + [("addend_stride", C.c_int32), ("pro_dy_out", C.c_void_p), ("pro_tot", C.POINTER(BnTot)),
+                   ("epi_totals", C.c_void_p), ("epi_replicas", C.c_int32)])
 
 
 class WgradJob(C.Structure):
@@ -66,6 +73,17 @@ _SIGS = {
     "frx_conv_stat_rows": (C.c_int, [C.POINTER(ConvDesc)]),
     "frx_stem_padded_dims": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "frx_conv_fwd": (C.c_int, [C.c_int, _P, C.POINTER(ConvDesc), _P, _P, _P, _P, C.c_int, _P, _P, C.c_int, _P]),
+    "frx_conv_fwd_tot": (C.c_int, [C.c_int, _P, C.POINTER(ConvDesc), _P, _P, C.POINTER(BnTot), C.c_int, _P, _P, C.c_int]),
+    "frx_block_merge_fwd_tot": (C.c_int, [C.c_int, _P, C.c_int, C.c_int64, C.c_int, _P, C.POINTER(BnTot), _P, C.POINTER(BnTot), _P, _P]),
+    "frx_bn_finalize_batched": (C.c_int, [C.c_int, _P, C.c_int, _P, C.c_int]),
+    "frx_bn_bwd_finalize_batched": (C.c_int, [C.c_int, _P, C.c_int, _P, C.c_int]),
+    "frx_bn_bwd_reduce_tot": (C.c_int, [C.c_int, _P, C.c_int, C.c_int64, C.c_int, _P, _P, _P, _P, _P, C.c_int,
+                                        _P, _P, _P, _P, C.c_int, C.c_int]),
+    "frx_bn_bwd_apply_tot": (C.c_int, [C.c_int, _P, C.c_int, C.c_int64, C.c_int, _P, _P, _P, _P, _P, C.c_int,
+                                       C.POINTER(BnTot), _P]),
+    "frx_stem_pool_fwd_tot": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.POINTER(BnTot), _P, _P]),
+    "frx_stem_bwd_reduce_tot": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int]),
+    "frx_stem_bwd_apply_tot": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P, _P, _P, C.POINTER(BnTot), _P]),
     "frx_conv_dgrad": (C.c_int, [C.c_int, _P, C.POINTER(ConvDesc), _P, _P, _P, _P]),
     "frx_conv_wgrad": (C.c_int, [C.c_int, _P, C.POINTER(ConvDesc), _P, _P, _P, C.c_int, _P, _P]),
     "frx_conv_dgrad_stat_rows": (C.c_int, [C.POINTER(ConvDesc)]),

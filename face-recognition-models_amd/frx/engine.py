@@ -16,6 +16,7 @@ import math
 from dataclasses import dataclass, field
 
 import os
+import struct
 import torch
 
 from . import ops
@@ -48,6 +49,12 @@ class ConvSpec:
     wt: torch.Tensor = None
     y: torch.Tensor = None
     stat_rows: int = 0
+    # BatchNorm statistics as replicated totals (csrc/bn_tot.h): forward (sum y, sum y^2) and backward (sum dz, sum dz*xhat)
+    R: int = 8
+    tot_f_buf: torch.Tensor = None
+    tot_b_buf: torch.Tensor = None
+    tot_f: object = None     # ops.bn_tot(...) views for the consumers
+    tot_b: object = None
 
     @property
     def Ho(self):
@@ -191,6 +198,12 @@ class ResNet50Engine:
         self.g_pool = torch.zeros_like(self.pool_out)        # gradient w.r.t. the max-pool output
         self.dy_stem = torch.zeros_like(self.stem.y)
         self.grouped_wgrad = os.environ.get("FRX_WGRAD_GROUPED", "1") != "0"
+        # bf16 speed mode: BatchNorm statistics travel as replicated totals the producers add into with float atomics
+        # and every consumer derives its constants from (no finalize launch per layer: -104 launches per step).  The fp32
+        # parity mode and FRX_BN_DETERMINISTIC=1 keep partial rows + finalize launches (bit-reproducible sums).
+        self.fused_bn = (dtype == BF16 and self.grouped_wgrad and os.environ.get("FRX_BN_DETERMINISTIC", "0") != "1")
+        if self.fused_bn:
+            self._plan_bn_totals()
         self.fused_stem_bwd = os.environ.get("FRX_FUSED_STEM_BWD", "1") != "0"
         self.mask_bits = os.environ.get("FRX_MASK_BITS", "1") != "0"
         self._wg_groups = None                               # planned at the end of __init__ (needs every buffer)
@@ -203,6 +216,63 @@ class ResNet50Engine:
             self.reset_parameters()
         if self.grouped_wgrad:
             self._plan_wgrad_groups()          # here, not at first use: the plan's host->device copy must not land inside a graph capture
+
+    # ------------------------------------------------------------------ BatchNorm statistics as replicated totals
+    def _plan_bn_totals(self):
+        dev = self.device
+        fed_by_reduce = {b.down.name for b in self.blocks if b.down is not None} | {self.blocks[-1].conv3.name}
+        for c in self.convs:
+            # Replicas: a producer block adds into row (its row-tile index mod R), and EVERY consumer block reads all R rows
+            # of every channel it needs -- so few rows where the layer has few row tiles (layer3: 98, layer4: 32: their
+            # adds are spread over the producer's run time anyway), 8 where it has hundreds, 16 for the stem (6272 tiles).
+            # The layers whose backward sums come from a stand-alone reduce launch (512 blocks that finish together: the
+            # projections' BatchNorms, the last bn3) keep 8.
+            tiles = (c.y.numel() // c.Co + 127) // 128
+            c.R = 16 if c.stem else (8 if (tiles >= 256 or c.name in fed_by_reduce) else (2 if tiles >= 64 else 1))
+        tot = sum(c.R * 2 * c.Co for c in self.convs)
+        self.bn_tot_f = torch.zeros(tot, device=dev)
+        self.bn_tot_b = torch.zeros(tot, device=dev)
+        o = 0
+        for c in self.convs:
+            n = c.R * 2 * c.Co
+            c.tot_f_buf, c.tot_b_buf = self.bn_tot_f[o:o + n], self.bn_tot_b[o:o + n]
+            o += n
+            count = c.y.numel() // c.Co
+            c.tot_f = ops.bn_tot(c.tot_f_buf, c.R, count, self.gamma(c), beta=self.beta(c), eps=BN_EPS)
+            c.tot_b = ops.bn_tot(c.tot_b_buf, c.R, count, self.gamma(c), mean=self._bn(self.bn_mean, c),
+                                 invstd=self._bn(self.bn_invstd, c))
+        f2i = lambda v: struct.unpack("i", struct.pack("f", v))[0]
+
+        def table(convs, fwd):
+            rows, blk = [], 0
+            for c in convs:
+                count = c.y.numel() // c.Co
+                if fwd:
+                    rows.append((c.tot_f_buf.data_ptr(), c.R, c.Co, count, self.gamma(c).data_ptr(), self.beta(c).data_ptr(),
+                                 self._bn(self.running_mean, c).data_ptr(), self._bn(self.running_var, c).data_ptr(),
+                                 self._bn(self.bn_mean, c).data_ptr(), self._bn(self.bn_invstd, c).data_ptr(),
+                                 self._bn(self.bn_scale, c).data_ptr(), self._bn(self.bn_shift, c).data_ptr(), blk,
+                                 f2i(BN_EPS), f2i(BN_MOMENTUM), 0))
+                else:
+                    rows.append((c.tot_b_buf.data_ptr(), c.R, c.Co, count, self.gamma(c).data_ptr(),
+                                 self._bn(self.bn_mean, c).data_ptr(), self._bn(self.bn_invstd, c).data_ptr(),
+                                 self.gamma(c, self.grads).data_ptr(), self.beta(c, self.grads).data_ptr(),
+                                 self._coef_of[c.name].data_ptr(), 0, 0, blk, 0, 0, 0))
+                blk += (c.Co + 255) // 256
+            return torch.tensor(rows, dtype=torch.int64, device=dev), len(rows), blk
+        # coefficient arrays: the blocks' own (the grouped weight gradients read them), the stem's in self.coef
+        self._coef_of = {self.stem.name: self.coef}
+        for b in self.blocks:
+            for c, k in ((b.conv3, 0), (b.conv2, 1), (b.conv1, 2), (b.down, 3)):
+                if c is not None:
+                    self._coef_of[c.name] = b.coefs[k]
+        self._bn_fin_fwd = table(self.convs, True)
+        groups = [[], [], []]
+        for bi, b in enumerate(self.blocks):
+            g = groups[0] if bi >= self.SPLIT_BLOCK else (groups[1] if bi >= LAYERS[0] else groups[2])
+            g += [c for c in (b.conv3, b.conv2, b.conv1, b.down) if c is not None]
+        groups[2].append(self.stem)
+        self._bn_fin_bwd = [table(g, False) for g in groups]
 
     # ------------------------------------------------------------------ parameter views
     def w_master(self, c: ConvSpec):
@@ -291,7 +361,10 @@ class ResNet50Engine:
         kw = {}
         if prev is not None:
             kw = dict(in_scale=self._bn(self.bn_scale, prev), in_shift=self._bn(self.bn_shift, prev), in_relu=True)
-        if self.training:
+        if self.training and self.fused_bn:
+            ops.conv_fwd_tot(c.desc, x, c.wk, c.y, in_bn=None if prev is None else prev.tot_f, stat_totals=c.tot_f_buf,
+                             stat_replicas=c.R)
+        elif self.training:
             ops.conv_fwd(c.desc, x, c.wk, c.y, stat_partial=self.stat_partial, **kw)
             count = c.y.numel() // c.Co
             ops.bn_finalize(self.stat_partial, c.stat_rows, c.Co, count, self.gamma(c), self.beta(c),
@@ -333,15 +406,25 @@ class ResNet50Engine:
         ops.input_prep(dt, images, self.xin)
         s = self.stem
         self._conv_bn(s, self.xin, None)
-        ops.stem_pool_fwd(dt, N, s.Ho, s.Ho, 64, s.y, self._bn(self.bn_scale, s), self._bn(self.bn_shift, s),
-                          self.pool_out, self.pool_arg)
+        fused = self.training and self.fused_bn
+        if fused:
+            ops.stem_pool_fwd_tot(dt, N, s.Ho, s.Ho, 64, s.y, s.tot_f, self.pool_out, self.pool_arg)
+        else:
+            ops.stem_pool_fwd(dt, N, s.Ho, s.Ho, 64, s.y, self._bn(self.bn_scale, s), self._bn(self.bn_shift, s),
+                              self.pool_out, self.pool_arg)
         x = self.pool_out
         for b in self.blocks:
             self._conv_bn(b.conv1, x, None)
             self._conv_bn(b.conv2, b.conv1.y, b.conv1)
             self._conv_bn(b.conv3, b.conv2.y, b.conv2)
             rows = b.out.numel() // b.conv3.Co
-            if b.down is not None:
+            if fused:
+                if b.down is not None:
+                    self._conv_bn(b.down, x, None)
+                ops.block_merge_fwd_tot(dt, rows, b.conv3.Co, b.conv3.y, b.conv3.tot_f, b.down.y if b.down is not None else x,
+                                        b.out, bnd=b.down.tot_f if b.down is not None else None,
+                                        mask=b.mask if self.mask_bits else None)
+            elif b.down is not None:
                 self._conv_bn(b.down, x, None)
                 ops.block_merge_fwd(dt, rows, b.conv3.Co, b.conv3.y, self._bn(self.bn_scale, b.conv3),
                                     self._bn(self.bn_shift, b.conv3), b.down.y, b.out,
@@ -351,6 +434,8 @@ class ResNet50Engine:
                 ops.block_merge_fwd(dt, rows, b.conv3.Co, b.conv3.y, self._bn(self.bn_scale, b.conv3),
                                     self._bn(self.bn_shift, b.conv3), x, b.out, mask=b.mask if (self.training and self.mask_bits) else None)
             x = b.out
+        if fused:       # one launch: the canonical mean / invstd / scale / shift arrays (the backward reads them), the
+            ops.bn_finalize_batched(*self._bn_fin_fwd)      # running statistics, and the totals zeroed for the next step
         hw = self.h_final * self.h_final
         ops.avgpool_fwd(dt, N, hw, 2048, x, self.pooled)
         ops.conv_fwd(self.fc_desc, self.pooled, self.fc_wk, self.feats, bias=self.fc_b(), out_f32=True)
@@ -379,14 +464,19 @@ class ResNet50Engine:
 
     def _finalize_bwd(self, c: ConvSpec, nrows_partial, coef):
         """partial sums (sum dz, sum dz*xhat) -> dgamma/dbeta (+=) and the affine coefficients of dy"""
+        if self.fused_bn:       # the consumers derive them from c.tot_b; the batched launch before the weight gradients closes
+            return
         rows = c.y.numel() // c.Co
         ops.bn_bwd_finalize(self.bwd_partial, nrows_partial, c.Co, rows, self.gamma(c), self._bn(self.bn_mean, c),
                             self._bn(self.bn_invstd, c), self.gamma(c, self.grads), self.beta(c, self.grads), coef)
 
     def _epi(self, c: ConvSpec, out=None):
         """keyword arguments of conv_dgrad_bn's epilogue for back-propagating through BN `c` (+ ReLU / merge)"""
-        kw = dict(epi_y=c.y, epi_mean=self._bn(self.bn_mean, c), epi_invstd=self._bn(self.bn_invstd, c),
-                  epi_partial=self.bwd_partial)
+        kw = dict(epi_y=c.y, epi_mean=self._bn(self.bn_mean, c), epi_invstd=self._bn(self.bn_invstd, c))
+        if self.fused_bn:
+            kw.update(epi_totals=c.tot_b_buf, epi_replicas=c.R)
+        else:
+            kw["epi_partial"] = self.bwd_partial
         if out is not None and out.dtype == torch.uint8:
             kw["epi_out_bits"] = out       # the block's 1-bit-per-element mask: 1/16 of reading its bf16 output again
         elif out is not None:
@@ -431,17 +521,30 @@ class ResNet50Engine:
         # broadcasts the pooled gradient itself (no [N, 4, 4, 2048] tensor, no launch for it)
         c3 = last.conv3
         rows3 = c3.y.numel() // c3.Co
-        ops.bn_bwd_reduce(dt, rows3, c3.Co, dpool, c3.y, self._bn(self.bn_mean, c3), self._bn(self.bn_invstd, c3),
-                          self.bwd_partial, out=last.out, dz_out=last.dz3, g_pool_hw=self.h_final * self.h_final)
+        if self.fused_bn:
+            ops.bn_bwd_reduce_tot(dt, rows3, c3.Co, dpool, c3.y, self._bn(self.bn_mean, c3), self._bn(self.bn_invstd, c3),
+                                  c3.tot_b_buf, c3.R, out=last.out, dz_out=last.dz3, g_pool_hw=self.h_final * self.h_final)
+        else:
+            ops.bn_bwd_reduce(dt, rows3, c3.Co, dpool, c3.y, self._bn(self.bn_mean, c3), self._bn(self.bn_invstd, c3),
+                              self.bwd_partial, out=last.out, dz_out=last.dz3, g_pool_hw=self.h_final * self.h_final)
         self._bw_npart = ops.bn_bwd_partial_rows(rows3, c3.Co)
         self._backward_blocks(len(self.blocks) - 1, self.SPLIT_BLOCK)
+        self._close_bn_bwd(0)
         self._run_wgrad_group(0)
 
     def backward_lower(self):
         self._backward_blocks(self.SPLIT_BLOCK - 1, 0)
         self._backward_stem()
+        self._close_bn_bwd(1)
         self._run_wgrad_group(1)
+        self._close_bn_bwd(2)
         self._run_wgrad_group(2)
+
+    def _close_bn_bwd(self, which):
+        """replicated totals of one group of BatchNorm layers -> dgamma / dbeta (+=) and the coefficient arrays the grouped
+        weight gradients read; the rows are zeroed for the next step (one launch)"""
+        if self.fused_bn:
+            ops.bn_bwd_finalize_batched(*self._bn_fin_bwd[which])
 
     def _backward_blocks(self, hi, lo):
         N, dt = self.N, self.dtype
@@ -461,7 +564,10 @@ class ResNet50Engine:
             self._finalize_bwd(c2, ops.conv_dgrad_stat_rows(c3.desc), C2)
             # conv2 (3x3): materialise dy2 once (9 taps would re-evaluate a prologue 9 times)
             rows2 = c2.y.numel() // c2.Co
-            ops.bn_bwd_apply(dt, rows2, c2.Co, dz2, c2.y, self._bn(self.bn_mean, c2), self._bn(self.bn_invstd, c2), C2, b.dy2)
+            if self.fused_bn:
+                ops.bn_bwd_apply_tot(dt, rows2, c2.Co, dz2, c2.y, c2.tot_b, b.dy2)
+            else:
+                ops.bn_bwd_apply(dt, rows2, c2.Co, dz2, c2.y, self._bn(self.bn_mean, c2), self._bn(self.bn_invstd, c2), C2, b.dy2)
             self._wgrad(c2, c1.y, b.dy2, x_bn=c1)
             dz1 = self._like(S[4], c1.y)
             ops.conv_dgrad_bn(c2.desc, b.dy2, c2.wt, dz1, **self._epi(c1))
@@ -469,8 +575,12 @@ class ResNet50Engine:
             addend, add_stride = dz3, 0
             if ds is not None:
                 rowsd = ds.y.numel() // ds.Co
-                ops.bn_bwd_reduce(dt, rowsd, ds.Co, dz3, ds.y, self._bn(self.bn_mean, ds), self._bn(self.bn_invstd, ds),
-                                  self.bwd_partial)
+                if self.fused_bn:
+                    ops.bn_bwd_reduce_tot(dt, rowsd, ds.Co, dz3, ds.y, self._bn(self.bn_mean, ds), self._bn(self.bn_invstd, ds),
+                                          ds.tot_b_buf, ds.R)
+                else:
+                    ops.bn_bwd_reduce(dt, rowsd, ds.Co, dz3, ds.y, self._bn(self.bn_mean, ds), self._bn(self.bn_invstd, ds),
+                                      self.bwd_partial)
                 self._finalize_bwd(ds, ops.bn_bwd_partial_rows(rowsd, ds.Co), CD)
                 if ds.desc_c is not None:
                     # stride-2 projection: only the even pixels of its input gradient are non-zero.  Compute those as a
@@ -500,13 +610,14 @@ class ResNet50Engine:
     def _bwd_1x1(self, b, c, dz, coef, x, dx, x_bn=None, addend=None, **epi):
         """input and weight gradient of a 1x1 conv whose BN backward is fused (dy = alpha*dz + beta*y + gam)"""
         dd = c.desc_c if c.desc_c is not None else c.desc      # dgrad geometry (compact for stride-2 projections)
+        pro = dict(pro_tot=c.tot_b) if self.fused_bn else dict(pro_coef=coef)
         if self._keeps_dy(c):
             dy = b.dyc[c.name]
-            ops.conv_dgrad_bn(dd, dz, c.wt, dx, addend=addend, pro_y=c.y, pro_coef=coef, pro_dy_out=dy, **epi)
+            ops.conv_dgrad_bn(dd, dz, c.wt, dx, addend=addend, pro_y=c.y, pro_dy_out=dy, **pro, **epi)
             self._wgrad(c, x, dy, x_bn=x_bn)
         else:
             self._wgrad(c, x, dz, x_bn=x_bn, pro_y=c.y, pro_coef=coef)
-            ops.conv_dgrad_bn(dd, dz, c.wt, dx, addend=addend, pro_y=c.y, pro_coef=coef, **epi)
+            ops.conv_dgrad_bn(dd, dz, c.wt, dx, addend=addend, pro_y=c.y, **pro, **epi)
 
     def _backward_stem(self):
         # stem: max-pool -> ReLU/BN -> conv weight gradient (no image gradient)
@@ -517,10 +628,14 @@ class ResNet50Engine:
             # two passes that re-gather from the pooled gradient instead of storing the 56x56 gradient and reading it twice
             sc, sh = self._bn(self.bn_scale, s), self._bn(self.bn_shift, s)
             mean, invstd = self._bn(self.bn_mean, s), self._bn(self.bn_invstd, s)
-            ops.stem_bwd_reduce(dt, N, s.Ho, s.Ho, 64, self.g_pool, self.pool_arg, s.y, sc, sh, mean, invstd, self.bwd_partial)
-            ops.bn_bwd_finalize(self.bwd_partial, ops.stem_bwd_partial_rows(), 64, s.y.numel() // 64, self.gamma(s), mean, invstd,
-                                self.gamma(s, self.grads), self.beta(s, self.grads), self.coef)
-            ops.stem_bwd_apply(dt, N, s.Ho, s.Ho, 64, self.g_pool, self.pool_arg, s.y, sc, sh, self.coef, self.dy_stem)
+            if self.fused_bn:
+                ops.stem_bwd_reduce_tot(dt, N, s.Ho, s.Ho, 64, self.g_pool, self.pool_arg, s.y, sc, sh, mean, invstd, s.tot_b_buf, s.R)
+                ops.stem_bwd_apply_tot(dt, N, s.Ho, s.Ho, 64, self.g_pool, self.pool_arg, s.y, sc, sh, s.tot_b, self.dy_stem)
+            else:
+                ops.stem_bwd_reduce(dt, N, s.Ho, s.Ho, 64, self.g_pool, self.pool_arg, s.y, sc, sh, mean, invstd, self.bwd_partial)
+                ops.bn_bwd_finalize(self.bwd_partial, ops.stem_bwd_partial_rows(), 64, s.y.numel() // 64, self.gamma(s), mean, invstd,
+                                    self.gamma(s, self.grads), self.beta(s, self.grads), self.coef)
+                ops.stem_bwd_apply(dt, N, s.Ho, s.Ho, 64, self.g_pool, self.pool_arg, s.y, sc, sh, self.coef, self.dy_stem)
         else:
             dpost = self._like(S[2], s.y)
             ops.stem_pool_bwd(dt, N, s.Ho, s.Ho, 64, self.g_pool, self.pool_arg, dpost)

@@ -310,6 +310,21 @@ def conv_fwd(d, x, w, y, in_scale=None, in_shift=None, in_relu=False, bias=None,
     return y
 
 
+def bn_tot(totals, replicas, count, gamma, beta=None, mean=None, invstd=None, eps=1e-5):
+    """frx_bn_tot: one BatchNorm layer's statistics as replicated totals [replicas][2][C] (the tensors must outlive it)"""
+    return _lib.BnTot(_pv(totals), _pv(gamma), _pv(beta), _pv(mean), _pv(invstd), int(replicas), float(count), float(eps), 0)
+
+
+def conv_fwd_tot(d, x, w, y, in_bn=None, in_relu=True, stat_totals=None, stat_replicas=0):
+    """conv_fwd with the prologue constants derived from `in_bn` (a BnTot) and the statistics of y added into stat_totals"""
+    bm, bn = _igemm_tile(d) if PROFILER is not None else (0, 0)
+    _timed(f"k_igemm<{_dt_name(d.dtype)},{bm},{bn}>", conv_flops(d), x, lambda: check(
+        _lib.lib().frx_conv_fwd_tot(_dev(x), _stream(x), C.byref(d), _p(x), _p(w), C.byref(in_bn) if in_bn is not None else None,
+                                    int(in_relu), _p(y), _p(stat_totals), int(stat_replicas)), "frx_conv_fwd_tot"),
+        nbytes=conv_bytes(d))
+    return y
+
+
 def conv_dgrad(d, dy, w_crsk, dx, addend=None):
     bm, bn = _igemm_tile(d, True) if PROFILER is not None else (0, 0)
     _timed(f"k_igemm<{_dt_name(d.dtype)},{bm},{bn}>", conv_flops(d), dy, lambda: check(
@@ -374,12 +389,15 @@ def conv_dgrad_stat_rows(d):
 
 def conv_dgrad_bn(d, dz, w_crsk, dx, addend=None, pro_y=None, pro_coef=None, epi_y=None, epi_out=None, epi_scale=None,
                   epi_shift=None, epi_mean=None, epi_invstd=None, epi_partial=None, pro_dy_out=None, addend_stride=0,
-                  epi_out_bits=None):
+                  epi_out_bits=None, pro_tot=None, epi_totals=None, epi_replicas=0):
     """dgrad with the BatchNorm backward fused in (prologue: dy = alpha*dz + beta*pro_y + gam; epilogue: mask +
-    per-channel reduce of the produced gradient)."""
+    per-channel reduce of the produced gradient).  pro_tot (a BnTot) instead of pro_coef / epi_totals [R][2][Ci] instead
+    of epi_partial: the replicated-totals form of the statistics (csrc/bn_tot.h)."""
     f = _lib.DgradFuse(*[0 if t is None else t.data_ptr() for t in
                          (pro_y, pro_coef, epi_y, epi_out, epi_scale, epi_shift, epi_mean, epi_invstd, epi_partial, epi_out_bits)],
-                       int(addend_stride), 0 if pro_dy_out is None else pro_dy_out.data_ptr())
+                       int(addend_stride), 0 if pro_dy_out is None else pro_dy_out.data_ptr(),
+                       C.pointer(pro_tot) if pro_tot is not None else None,
+                       0 if epi_totals is None else epi_totals.data_ptr(), int(epi_replicas))
     bm, bn = _igemm_tile(d, True) if PROFILER is not None else (0, 0)
     _timed(f"k_igemm<{_dt_name(d.dtype)},{bm},{bn}>", conv_flops(d), dz, lambda: check(
         _lib.lib().frx_conv_dgrad_bn(_dev(dz), _stream(dz), C.byref(d), _p(dz), _p(w_crsk), _p(addend), _p(dx),
@@ -418,6 +436,49 @@ def block_merge_fwd(dtype, rows, Cc, y3, s3, b3, idn, out, sd=None, bd=None, mas
         check(_lib.lib().frx_block_merge_fwd_mask(_dev(y3), _stream(y3), dtype, rows, Cc, _p(y3), _p(s3), _p(b3), _p(idn),
                                                   _p(sd), _p(bd), _p(out), _p(mask)), "frx_block_merge_fwd_mask")
     return out
+
+
+def block_merge_fwd_tot(dtype, rows, Cc, y3, bn3, idn, out, bnd=None, mask=None):
+    check(_lib.lib().frx_block_merge_fwd_tot(_dev(y3), _stream(y3), dtype, rows, Cc, _p(y3), C.byref(bn3), _p(idn),
+                                             C.byref(bnd) if bnd is not None else None, _p(out), _p(mask)), "frx_block_merge_fwd_tot")
+    return out
+
+
+def bn_finalize_batched(table, n, total_blocks):
+    check(_lib.lib().frx_bn_finalize_batched(_dev(table), _stream(table), n, _p(table), total_blocks), "frx_bn_finalize_batched")
+
+
+def bn_bwd_finalize_batched(table, n, total_blocks):
+    check(_lib.lib().frx_bn_bwd_finalize_batched(_dev(table), _stream(table), n, _p(table), total_blocks), "frx_bn_bwd_finalize_batched")
+
+
+def bn_bwd_reduce_tot(dtype, rows, Cc, g, y, mean, invstd, totals, replicas, out=None, scale=None, shift=None, relu=False,
+                      dz_out=None, g_pool_hw=0):
+    check(_lib.lib().frx_bn_bwd_reduce_tot(_dev(g), _stream(g), dtype, rows, Cc, _p(g), _p(y), _p(out), _p(scale), _p(shift),
+                                           int(relu), _p(mean), _p(invstd), _p(dz_out), _p(totals), int(replicas), int(g_pool_hw)),
+          "frx_bn_bwd_reduce_tot")
+
+
+def bn_bwd_apply_tot(dtype, rows, Cc, g, y, bn, dy, out=None, scale=None, shift=None, relu=False):
+    check(_lib.lib().frx_bn_bwd_apply_tot(_dev(g), _stream(g), dtype, rows, Cc, _p(g), _p(y), _p(out), _p(scale), _p(shift),
+                                          int(relu), C.byref(bn), _p(dy)), "frx_bn_bwd_apply_tot")
+    return dy
+
+
+def stem_pool_fwd_tot(dtype, N, H, W, Cc, y, bn, out, argmax):
+    check(_lib.lib().frx_stem_pool_fwd_tot(_dev(y), _stream(y), dtype, N, H, W, Cc, _p(y), C.byref(bn), _p(out), _p(argmax)),
+          "frx_stem_pool_fwd_tot")
+
+
+def stem_bwd_reduce_tot(dtype, N, H, W, Cc, dout, argmax, y, scale, shift, mean, invstd, totals, replicas):
+    check(_lib.lib().frx_stem_bwd_reduce_tot(_dev(dout), _stream(dout), dtype, N, H, W, Cc, _p(dout), _p(argmax), _p(y), _p(scale),
+                                             _p(shift), _p(mean), _p(invstd), _p(totals), int(replicas)), "frx_stem_bwd_reduce_tot")
+
+
+def stem_bwd_apply_tot(dtype, N, H, W, Cc, dout, argmax, y, scale, shift, bn, dy):
+    check(_lib.lib().frx_stem_bwd_apply_tot(_dev(dout), _stream(dout), dtype, N, H, W, Cc, _p(dout), _p(argmax), _p(y), _p(scale),
+                                            _p(shift), C.byref(bn), _p(dy)), "frx_stem_bwd_apply_tot")
+    return dy
 
 
 def bn_bwd_partial_rows(rows, Cc):

@@ -46,9 +46,9 @@ enum frx_head_kind { FRX_ARC = 0, FRX_COS = 1, FRX_SPHERE = 2, FRX_CURR = 3,
 
 /* ---------------------------------------------------------------- diagnostics */
 int frx_version(void);
-/* sizeof(frx_head_desc), sizeof(frx_conv_desc), sizeof(frx_dgrad_fuse), sizeof(frx_wgrad_job): lets a binding verify its
- * own struct layouts (ctypes / cgo / JNI) against the library it loaded */
-int frx_struct_sizes(int64_t sizes[4]);
+/* sizeof(frx_head_desc), sizeof(frx_conv_desc), sizeof(frx_dgrad_fuse), sizeof(frx_wgrad_job), sizeof(frx_bn_tot), 0, 0, 0:
+ * lets a binding verify its own struct layouts (ctypes / cgo / JNI) against the library it loaded */
+int frx_struct_sizes(int64_t sizes[8]);
 const char* frx_last_error(void);
 /* props[0]=CU count, [1]=clock kHz, [2]=LDS bytes/CU, [3]=wavefront size, [4]=gcnArch is gfx950 (0/1) */
 int frx_device_props(int device, int64_t props[8]);
@@ -198,6 +198,27 @@ int frx_conv_stat_rows(const frx_conv_desc* d);
  * launches for this layer -- what the profiling labels and the stat-row counts are derived from */
 int frx_conv_tile(const frx_conv_desc* d, int dgrad, int* bm, int* bn);
 int frx_stem_padded_dims(int Hi, int Wi, int* Hp, int* Wp);
+/* Train-mode BatchNorm statistics as REPLICATED TOTALS (csrc/bn_tot.h; replaces the 53 + 53 per-layer finalize launches of
+ * a training step, i.e. the statistics half of every nn.BatchNorm2d forward / backward of backbones.py:16-18).  A producing
+ * kernel ADDS its per-channel sums with float atomics into `replicas` rows  totals[replicas][2][C]  (forward: sum y, sum y^2;
+ * backward: sum dz, sum dz*xhat); every consuming kernel derives the constants it needs from those rows while it sets up;
+ * frx_bn_finalize_batched / frx_bn_bwd_finalize_batched write the canonical per-channel arrays once per pass and zero the
+ * rows.  Sums depend on arrival order in the last bits: the bit-reproducible path is stat_partial + frx_bn_finalize. */
+typedef struct frx_bn_tot {
+  const float* totals;   /* [replicas][2][C] */
+  const float* gamma;    /* [C] */
+  const float* beta;     /* [C]  forward consumers (scale / shift) */
+  const float* mean;     /* [C]  backward consumers (alpha / beta / gam): the arrays frx_bn_finalize_batched wrote */
+  const float* invstd;   /* [C]  backward consumers */
+  int32_t replicas;      /* a power of two: few rows for layers with few row tiles (every consumer block reads all of them) */
+  float count;           /* elements per channel */
+  float eps;             /* forward */
+  int32_t reserved;
+} frx_bn_tot;
+/* frx_conv_fwd with the prologue constants taken from `in_bn` (NULL: no prologue) and the statistics of y ADDED into
+ * stat_totals [stat_replicas][2][Co] (NULL: none) */
+int frx_conv_fwd_tot(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x, const void* w_krsc,
+                     const frx_bn_tot* in_bn, int in_relu, void* y, float* stat_totals, int stat_replicas);
 /* y = conv(f(x), w) [+ bias]; out_f32 stores y as fp32 (the fc layer feeding the head) */
 int frx_conv_fwd(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x, const void* w_krsc,
                  const float* in_scale, const float* in_shift, int in_relu, const float* bias, void* y,
@@ -228,6 +249,9 @@ typedef struct frx_dgrad_fuse {
   void* pro_dy_out;          /* optional (1x1 convs, with pro_y): the prologue's dy = alpha*dz + beta*y + gam is also stored
                                 here ([N,Ho,Wo,Co], dtype T) by the first column of tiles, so that frx_conv_wgrad can read
                                 dy without re-evaluating the BN backward (and without reading two tensors) */
+  const frx_bn_tot* pro_tot; /* instead of pro_coef (with pro_y): alpha / beta / gam derived from replicated totals */
+  float* epi_totals;         /* instead of epi_partial: (sum dz, sum dz*xhat) ADDED into [epi_replicas][2][Ci] */
+  int32_t epi_replicas;
 } frx_dgrad_fuse;
 int frx_conv_dgrad_stat_rows(const frx_conv_desc* d);
 int frx_conv_dgrad_bn(int device, frx_stream_t stream, const frx_conv_desc* d, const void* dz, const void* w_crsk,
@@ -282,6 +306,17 @@ int frx_block_merge_fwd(int device, frx_stream_t stream, int dtype, int64_t rows
 int frx_block_merge_fwd_mask(int device, frx_stream_t stream, int dtype, int64_t rows, int C, const void* y3,
                              const float* s3, const float* b3, const void* idn, const float* sd, const float* bd,
                              void* out, uint8_t* mask);
+/* the same with the BatchNorm constants derived from replicated totals (bnd NULL: identity block); mask may be NULL */
+int frx_block_merge_fwd_tot(int device, frx_stream_t stream, int dtype, int64_t rows, int C, const void* y3,
+                            const frx_bn_tot* bn3, const void* idn, const frx_bn_tot* bnd, void* out, uint8_t* mask);
+/* every listed BatchNorm layer in ONE launch (one thread per channel): totals -> mean / invstd / scale / shift (+ running
+ * statistics), then the rows are zeroed.  table_dev [n][16] int64 = {totals, replicas, C, count, gamma, beta,
+ * running_mean | 0, running_var | 0, mean, invstd, scale, shift, index of the layer's first block (256 channels per
+ * block), eps as float bits, momentum as float bits, 0}; total_blocks = sum of ceil(C / 256). */
+int frx_bn_finalize_batched(int device, frx_stream_t stream, int n, const int64_t* table_dev, int total_blocks);
+/* backward twin: totals (sum dz, sum dz*xhat) -> dgamma +=, dbeta +=, coef [3][C]; rows zeroed.  table_dev [n][16] int64 =
+ * {totals, replicas, C, count, gamma, mean, invstd, dgamma | 0, dbeta | 0, coef, 0, 0, first block, 0, 0, 0} */
+int frx_bn_bwd_finalize_batched(int device, frx_stream_t stream, int n, const int64_t* table_dev, int total_blocks);
 /* BatchNorm backward in three steps.  dz = g*mask with mask = (out>0) if out given, else
  * (scale*y+shift>0) if relu, else 1.
  *   reduce   -> partial [frx_bn_bwd_partial_rows][2][C] = (sum dz, sum dz*xhat); optional dz_out
@@ -295,6 +330,13 @@ int frx_bn_bwd_partial_rows(int64_t rows, int C);
 int frx_bn_bwd_reduce(int device, frx_stream_t stream, int dtype, int64_t rows, int C, const void* g, const void* y,
                       const void* out, const float* scale, const float* shift, int relu, const float* mean,
                       const float* invstd, void* dz_out, float* partial, int g_pool_hw);
+/* frx_bn_bwd_reduce adding into replicated totals [replicas][2][C] instead of writing partial rows */
+int frx_bn_bwd_reduce_tot(int device, frx_stream_t stream, int dtype, int64_t rows, int C, const void* g, const void* y,
+                          const void* out, const float* scale, const float* shift, int relu, const float* mean,
+                          const float* invstd, void* dz_out, float* totals, int replicas, int g_pool_hw);
+/* frx_bn_bwd_apply with alpha / beta / gam derived from replicated totals */
+int frx_bn_bwd_apply_tot(int device, frx_stream_t stream, int dtype, int64_t rows, int C, const void* g, const void* y,
+                         const void* out, const float* scale, const float* shift, int relu, const frx_bn_tot* bn, void* dy);
 int frx_bn_bwd_finalize(int device, frx_stream_t stream, const float* partial, int nblk, int C, int64_t count,
                         const float* gamma, const float* mean, const float* invstd, float* dgamma, float* dbeta,
                         float* coef);
@@ -303,6 +345,8 @@ int frx_bn_bwd_apply(int device, frx_stream_t stream, int dtype, int64_t rows, i
                      const float* invstd, const float* coef, void* dy);
 int frx_stem_pool_fwd(int device, frx_stream_t stream, int dtype, int N, int H, int W, int C, const void* y,
                       const float* scale, const float* shift, void* out, uint8_t* argmax);
+int frx_stem_pool_fwd_tot(int device, frx_stream_t stream, int dtype, int N, int H, int W, int C, const void* y,
+                          const frx_bn_tot* bn, void* out, uint8_t* argmax);
 int frx_stem_pool_bwd(int device, frx_stream_t stream, int dtype, int N, int H, int W, int C, const void* dout,
                       const uint8_t* argmax, void* dpost);
 /* The stem's backward in two passes that never store the full-resolution gradient: the max-pool gather of
@@ -317,6 +361,12 @@ int frx_stem_bwd_reduce(int device, frx_stream_t stream, int dtype, int N, int H
 int frx_stem_bwd_apply(int device, frx_stream_t stream, int dtype, int N, int H, int W, int C, const void* dout,
                        const uint8_t* argmax, const void* y, const float* scale, const float* shift, const float* coef,
                        void* dy);
+int frx_stem_bwd_reduce_tot(int device, frx_stream_t stream, int dtype, int N, int H, int W, int C, const void* dout,
+                            const uint8_t* argmax, const void* y, const float* scale, const float* shift, const float* mean,
+                            const float* invstd, float* totals, int replicas);
+int frx_stem_bwd_apply_tot(int device, frx_stream_t stream, int dtype, int N, int H, int W, int C, const void* dout,
+                           const uint8_t* argmax, const void* y, const float* scale, const float* shift,
+                           const frx_bn_tot* bn, void* dy);
 int frx_avgpool_fwd(int device, frx_stream_t stream, int dtype, int N, int HW, int C, const void* x, void* out);
 int frx_avgpool_bwd(int device, frx_stream_t stream, int dtype, int N, int HW, int C, const void* dpool, void* dx);
 

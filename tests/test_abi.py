@@ -49,9 +49,10 @@ def test_struct_layouts_match_the_library():
     """the ctypes mirrors of the boundary structs have the sizes the C compiler gave them (padding included)"""
     import ctypes as C
     from frx import _lib
-    sizes = (C.c_int64 * 4)()
+    sizes = (C.c_int64 * 8)()
     assert _lib.lib().frx_struct_sizes(sizes) == 0
-    assert list(sizes) == [C.sizeof(_lib.HeadDesc), C.sizeof(_lib.ConvDesc), C.sizeof(_lib.DgradFuse), C.sizeof(_lib.WgradJob)]
+    assert list(sizes) == [C.sizeof(_lib.HeadDesc), C.sizeof(_lib.ConvDesc), C.sizeof(_lib.DgradFuse), C.sizeof(_lib.WgradJob),
+                           C.sizeof(_lib.BnTot), 0, 0, 0]
 
 
 def test_wgrad_group_planning_is_host_logic():

@@ -11,13 +11,17 @@ DEV = "cuda:0"
 N, C = 256, 10575
 
 
-def _engine(grouped=True, seed=0):
+def _engine(grouped=True, seed=0, deterministic=False):
+    """deterministic: BatchNorm statistics as partial rows + finalize launches (bit-reproducible) instead of the default
+    replicated totals the producers add into with float atomics (csrc/bn_tot.h)"""
     from frx import engine as E, ops
     os.environ["FRX_WGRAD_GROUPED"] = "1" if grouped else "0"
+    os.environ["FRX_BN_DETERMINISTIC"] = "1" if deterministic else "0"
     try:
         return E.FaceEngine("arcface", C, N, dtype=ops.BF16, device=DEV, seed=seed)
     finally:
         os.environ.pop("FRX_WGRAD_GROUPED", None)
+        os.environ.pop("FRX_BN_DETERMINISTIC", None)
 
 
 def _batch(seed=0):
@@ -26,12 +30,13 @@ def _batch(seed=0):
 
 
 def test_forward_is_bit_reproducible_and_finite():
-    eng = _engine()
+    eng = _engine(deterministic=True)
+    assert not eng.net.fused_bn
     x, y = _batch()
     a = eng.forward_loss(x, y)
     f1, l1 = a["feats"].clone(), a["loss"].clone()
     b = eng.forward_loss(x, y)
-    assert torch.equal(b["feats"], f1) and torch.equal(b["loss"], l1), "the forward has no atomics: it must replay bit for bit"
+    assert torch.equal(b["feats"], f1) and torch.equal(b["loss"], l1), "the deterministic forward has no atomics: it must replay bit for bit"
     assert torch.isfinite(f1).all() and 5.0 < l1.item() < 100.0
     for c in eng.net.convs:                      # train-mode BN really normalised every layer of this batch
         m, s = eng.net._bn(eng.net.bn_mean, c), eng.net._bn(eng.net.bn_invstd, c)
@@ -61,7 +66,7 @@ def test_grouped_and_per_layer_weight_gradients_agree():
     """Same upstream gradient into both schedules: the dgrad chain has no atomics, so every dy is bit-identical and the
     weight gradients may differ only by the order of their fp32 atomics.  (Through the head the comparison is useless:
     its atomics perturb dfeat by 1e-7, bf16 rounding flips amplify that to ~2e-2 by the stem -- measured.)"""
-    e1, e2 = _engine(grouped=True), _engine(grouped=False)
+    e1, e2 = _engine(grouped=True, deterministic=True), _engine(grouped=False, deterministic=True)
     assert e1.net.grouped_wgrad and not e2.net.grouped_wgrad
     x, y = _batch(2)
     g = torch.Generator().manual_seed(9)
@@ -148,9 +153,13 @@ def test_graph_replay_stays_finite_unsynchronised():
 # ------------------------------------------------------------------------------------------------------------------
 # BASELINE configs[2] / [3] / [4] at their per-GPU sizes ("configs untested at full size")
 # ------------------------------------------------------------------------------------------------------------------
-def _face_engine(kind, n, c, seed=0):
+def _face_engine(kind, n, c, seed=0, deterministic=False):
     from frx import engine as E, ops
-    return E.FaceEngine(kind, c, n, dtype=ops.BF16, device=DEV, seed=seed)
+    os.environ["FRX_BN_DETERMINISTIC"] = "1" if deterministic else "0"
+    try:
+        return E.FaceEngine(kind, c, n, dtype=ops.BF16, device=DEV, seed=seed)
+    finally:
+        os.environ.pop("FRX_BN_DETERMINISTIC", None)
 
 
 def _face_batch(n, c, seed=0):
@@ -182,7 +191,9 @@ def test_cosface_full_size_step_configs2_per_gpu_shape():
     a = eng.forward_loss(x, y, want_logits=True)
     f1, l1, lg = a["feats"].clone(), a["loss"].clone(), a["logits"].clone()
     b = eng.forward_loss(x, y)
-    assert torch.equal(b["feats"], f1) and torch.equal(b["loss"], l1)
+    # (default path: BatchNorm sums by float atomics -- equal to rounding, not bit for bit; the deterministic switch is
+    # covered by test_forward_is_bit_reproducible_and_finite)
+    assert (b["feats"] - f1).abs().max().item() < 2e-2 * f1.abs().max().item() and abs(b["loss"].item() - l1.item()) < 2e-2
     ref_loss, cos = _head_reference_loss(eng, f1, y, "cosface")
     assert abs(l1.item() - ref_loss) < 1e-3
     z = cos.clone(); z[torch.arange(N, device=DEV), y] -= eng.m
