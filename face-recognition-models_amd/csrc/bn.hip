@@ -632,7 +632,7 @@ static inline int row_grid(long rows, int C, int V) {
 // Row sweeps whose blocks first derive their constants from replicated totals run fewer, longer-lived blocks: the
 // derivation is paid per block (FRX_TOT_ROW_GRID: tuning aid, read per launch)
 static inline int tot_row_grid(int grid) {
-  int cap = 1024;
+  int cap = 512;
   if (const char* e = getenv("FRX_TOT_ROW_GRID")) cap = atoi(e) > 0 ? atoi(e) : cap;
   return grid < cap ? grid : cap;
 }

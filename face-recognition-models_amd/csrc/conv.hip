@@ -35,7 +35,7 @@ static int launch_igemm(hipStream_t st, ConvArgs a, int dtype) {
   }
   a.tilesN = cdiv(a.Ncol, c.bn);
   const bool has_pro = a.in_scale || a.in_tot.tot || a.X2;
-  c.ns = dma_stages(c, !has_pro, a.mode == MODE_STEM);
+  c.ns = dma_stages(c, !has_pro, a.mode == MODE_STEM, (long)a.tilesM * a.tilesN);
   const int grid = (int)round_up(a.tilesM, 8) * a.tilesN;
   int epi = EPI_PLAIN;
   if (a.epi_bnbwd) epi = (a.e_out || a.e_bits) ? EPI_BNBWD_OUT : EPI_BNBWD;

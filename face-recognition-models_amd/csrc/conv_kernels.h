@@ -281,9 +281,9 @@ template <typename T, int BM, int BN, int WM, int WN, int MODE, int PRO, int EPI
 #ifndef FRX_OCC4W            // tuning aid: blocks per CU the four-wave tiles are compiled for (0: the table below)
 #define FRX_OCC4W 0
 #endif
-__global__ __launch_bounds__(64 * WM * WN, (KC == 128 || PD > 3) ? 2 : (WM * WN == 8 ? 4 : (FRX_OCC4W ? FRX_OCC4W : ((PRO == 0 && EPI != EPI_BNBWD_OUT && !ADD) ? 3 : 2)))) void k_igemm(ConvArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, (NS > 4) ? (WM * WN) / 4 : (KC == 128 || PD > 3) ? 2 : (WM * WN == 8 ? 4 : (FRX_OCC4W ? FRX_OCC4W : ((PRO == 0 && EPI != EPI_BNBWD_OUT && !ADD) ? 3 : 2)))) void k_igemm(ConvArgs a) {
   constexpr bool DMA = NS > 0;
-  static_assert(!DMA || (PRO == 0 && MODE != MODE_STEM && NS >= 3 && NS <= 4), "LDS-DMA staging: prologue-free launches, 3 or 4 stages");
+  static_assert(!DMA || (PRO == 0 && MODE != MODE_STEM && NS >= 3 && NS <= 8), "LDS-DMA staging: prologue-free launches, 3 to 8 stages");
   constexpr int VEC = TT<T>::VEC, CE = KC / (int)sizeof(T);      // elements per 16-byte load; elements per K-chunk
   constexpr int CPR = KC / 16;                                   // 16-byte slots per row of the LDS image
   constexpr int NT = 64 * WM * WN, RPP = NT / CPR;     // threads; tile rows staged per pass (CPR x 16-byte loads per row)

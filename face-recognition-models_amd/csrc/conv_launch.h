@@ -11,15 +11,20 @@ struct TileCfg { int bm, bn, waves, kc; int ns = 0; };       // block tile (pixe
 
 // LDS-DMA staging (k_igemm<..., NS>) exists for the prologue-free launches on the two production tiles; FRX_IGEMM_DMA=0
 // switches it off, =3 / =4 picks the stage count of the 128x128 tile (tuning aid, read per launch)
-static inline int dma_stages(const TileCfg& c, bool prologue_free, bool stem) {
+// Stage count: a chunk issued at step k is consumed at step k + NS - 2, so NS - 2 steps of MFMA work cover its flight.
+// In a training step the operands come from HBM / the Infinity Cache (~1-2 us under load, 10x a step's MFMA time): four
+// stages (what two blocks per CU can hold) hide a third of it, so launches with at most one block per CU take the deep
+// ring (8 x 16 KB / 6 x 24 KB of the CU's 160 KB).  FRX_IGEMM_DMA=0: off; =N: force N stages where instantiated.
+static inline int dma_stages(const TileCfg& c, bool prologue_free, bool stem, long tiles) {
   if (!prologue_free || stem) return 0;
   const bool t128 = c.bm == 128 && c.bn == 128 && c.kc == 64, t64 = c.bm == 64 && c.bn == 128 && c.kc == 128;
   if (!t128 && !t64) return 0;
-  int ns = t128 ? 4 : 3;
+  int ns = tiles <= 256 ? (t128 ? 8 : 6) : (t128 ? 4 : 0);      // (64x128 with more than a block per CU: three stages hide too little -- register ring)
   if (const char* e = getenv("FRX_IGEMM_DMA")) {
     const int v = atoi(e);
     if (v == 0) return 0;
-    if (t128 && (v == 3 || v == 4)) ns = v;
+    if (t128 && (v == 4 || v == 8)) ns = v;
+    if (t64 && (v == 3 || v == 6)) ns = v;
   }
   return ns;
 }
@@ -93,8 +98,9 @@ int launch_wgrad_grouped(hipStream_t st, int dtype, const WgradArgs* layers, con
 #define FRX_IGEMM_LAUNCH_DMA(T_, MODE_, EPI_, ADD_)                                                                        \
   do {                                                                                                                     \
     if (c.ns == 4 && c.bm == 128 && c.bn == 128) FRX_IGEMM_KN(T_, 128, 128, 2, 4, MODE_, 0, EPI_, ADD_, 64, 4);            \
-    else if (c.ns == 3 && c.bm == 128 && c.bn == 128) FRX_IGEMM_KN(T_, 128, 128, 2, 4, MODE_, 0, EPI_, ADD_, 64, 3);       \
+    else if (c.ns == 8 && c.bm == 128 && c.bn == 128) FRX_IGEMM_KN(T_, 128, 128, 2, 4, MODE_, 0, EPI_, ADD_, 64, 8);       \
     else if (c.ns == 3 && c.bm == 64 && c.bn == 128 && c.kc == 128) FRX_IGEMM_KN(T_, 64, 128, 1, 4, MODE_, 0, EPI_, ADD_, 128, 3); \
+    else if (c.ns == 6 && c.bm == 64 && c.bn == 128 && c.kc == 128) FRX_IGEMM_KN(T_, 64, 128, 1, 4, MODE_, 0, EPI_, ADD_, 128, 6); \
     else FRX_IGEMM_LAUNCH(T_, MODE_, 0, EPI_, ADD_);                                                                       \
   } while (0)
 #define FRX_IGEMM_DT_DMA(MODE_, EPI_, ADD_)                                     \

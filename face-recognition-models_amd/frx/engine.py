@@ -228,7 +228,8 @@ class ResNet50Engine:
             # The layers whose backward sums come from a stand-alone reduce launch (512 blocks that finish together: the
             # projections' BatchNorms, the last bn3) keep 8.
             tiles = (c.y.numel() // c.Co + 127) // 128
-            c.R = 16 if c.stem else (8 if (tiles >= 256 or c.name in fed_by_reduce) else (2 if tiles >= 64 else 1))
+            big = int(os.environ.get("FRX_BN_R", "8"))          # (tuning aid)
+            c.R = 2 * big if c.stem else (big if (tiles >= 256 or c.name in fed_by_reduce) else (2 if tiles >= 64 else 1))
         tot = sum(c.R * 2 * c.Co for c in self.convs)
         self.bn_tot_f = torch.zeros(tot, device=dev)
         self.bn_tot_b = torch.zeros(tot, device=dev)

@@ -10,7 +10,7 @@ import torch
 from frx import ops
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 DEV = "cuda:0"
-VARIANTS = ["0", "3", "4"]
+VARIANTS = ["0", "4", "8"]      # (3 / 6 on the 64x128 tile)
 # (Ci, Co, k, stride, Hi)
 SHAPES = [(256, 64, 1, 1, 28), (256, 128, 1, 1, 28), (512, 128, 1, 1, 14), (128, 128, 3, 1, 14), (1024, 256, 1, 1, 7), (256, 256, 3, 1, 7),
           (2048, 512, 1, 1, 4), (512, 512, 3, 1, 4), (256, 512, 1, 2, 28), (512, 1024, 1, 2, 14), (64, 64, 3, 1, 28), (128, 128, 3, 2, 28),

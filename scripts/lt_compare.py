@@ -7,7 +7,7 @@ def rows(f):
     for l in open(f):
         p = l.split()
         if len(p) >= 9 and p[0].startswith("conv"):
-            out.append((p[0], p[1], tuple(p[2:7]), float(p[7])))
+            out.append((p[0].replace("conv_fwd_tot", "conv_fwd"), p[1], tuple(p[2:7]), float(p[7])))
     return out
 fs = sys.argv[1:]
 R = [rows(f) for f in fs]
