@@ -36,6 +36,13 @@ static inline BnTot bn_tot_arg(const frx_bn_tot* t) {
   return b;
 }
 
+// field-wise copy (the source may live in another address space: the kernarg segment)
+template <typename S> __device__ __forceinline__ BnTot bn_tot_copy(const S& s) {
+  BnTot b;
+  b.tot = s.tot; b.gamma = s.gamma; b.beta = s.beta; b.mean = s.mean; b.invstd = s.invstd; b.R = s.R; b.eps = s.eps; b.inv_count = s.inv_count;
+  return b;
+}
+
 // The closing arithmetic of BatchNorm statistics, shared by EVERY kernel that turns sums into constants (the per-layer
 // finalize kernels, the batched ones, and each consumer's prologue): one definition, so they agree bit for bit.
 // forward: channel sums (s, q) of y and y^2 -> mean, biased variance (double), invstd = rsqrt(var + eps) in float (one

@@ -36,7 +36,22 @@ static int launch_igemm(hipStream_t st, ConvArgs a, int dtype) {
   a.tilesN = cdiv(a.Ncol, c.bn);
   const bool has_pro = a.in_scale || a.in_tot.tot || a.X2;
   c.ns = dma_stages(c, !has_pro, a.mode == MODE_STEM, (long)a.tilesM * a.tilesN);
-  const int grid = (int)round_up(a.tilesM, 8) * a.tilesN;
+  a.nvb = (int)round_up(a.tilesM, 8) * a.tilesN;
+  // Persistent blocks (conv_kernels.h: run_tile) when the launch has more tiles than fit on the chip at once and its
+  // statistics (if any) go to replicated totals: `cap` resident blocks walk the tiles with a fixed stride.  cap / 8 is a
+  // multiple of tilesN (a block stays in one column of tiles).  FRX_IGEMM_PERSIST=0: off; =N: N blocks per CU.
+  int grid = a.nvb;
+  {
+    int per_cu = c.waves == 8 ? 2 : 3;
+    if (const char* e = getenv("FRX_IGEMM_PERSIST")) per_cu = atoi(e);
+    const int cap = per_cu * 256;
+    // (the instantiated persistent variants: forward only.  Measured per launch inside a training step, persistent vs one
+    // tile per block: the prologue-fed pointwise forwards of layer1/2 gain 7-9 % (the 64->256 conv3: 42.1 -> 38.9 us),
+    // the input gradients LOSE 8-15 % -- their epilogues are where the registers run out, and a tile loop without
+    // cross-tile prefetch only adds live state there: profiles/r03_persist_layer_times.txt)
+    const bool tile_ok = c.kc == 64 && c.bm == 128 && !c.ns && a.mode == MODE_FWD;
+    if (per_cu > 0 && tile_ok && !a.stat_partial && a.nvb > cap && (cap / 8) % a.tilesN == 0) grid = cap;
+  }
   int epi = EPI_PLAIN;
   if (a.epi_bnbwd) epi = (a.e_out || a.e_bits) ? EPI_BNBWD_OUT : EPI_BNBWD;
   else if (a.stat_partial || a.stat_tot) epi = EPI_STATS;

@@ -80,6 +80,7 @@ struct ConvArgs {
   int M;
   int mode;
   int tilesM, tilesN;
+  int nvb;                   // tiles incl. the padding of tilesM to a multiple of 8 ("virtual blocks"); the grid may be smaller (persistent blocks)
   unsigned xbytes, wbytes;   // sizes of X (and X2) and W in bytes: buffer-load bounds (out-of-range reads return 0)
   // Stride-2 input gradient by output-pixel PARITY CLASS (dgrad of a strided RxS conv): output pixel (h, w) only
   // receives taps with r = h + pad, s = w + pad (mod 2), so the four classes (h & 1, w & 1) are dense convolutions over a
@@ -274,14 +275,14 @@ static inline unsigned igemm_pro_lds(int pro, int Kc) { return pro ? (pro == 2 ?
 
 // MODE (gather geometry) and PRO (BN+ReLU prologue) are compile-time so the steady-state K loop is
 // straight-line code: hipcc then keeps counted s_waitcnt vmcnt(N) for the register ring.
-template <typename T, int BM, int BN, int WM, int WN, int MODE, int PRO, int EPI, bool ADD, int KC = 64, int PD = 3, int NS = 0>   // PRO: 0 none, 1 BN+ReLU, 2 BN-backward affine; KC: bytes of the contraction axis per row and K-chunk; PD: ring depth; NS > 0: LDS-DMA staging into a ring of NS LDS stages (PRO == 0 only) instead of the register ring
+template <typename T, int BM, int BN, int WM, int WN, int MODE, int PRO, int EPI, bool ADD, int KC = 64, int PD = 3, int NS = 0, bool PERSIST = false>   // PRO: 0 none, 1 BN+ReLU, 2 BN-backward affine; KC: bytes of the contraction axis per row and K-chunk; PD: ring depth; NS > 0: LDS-DMA staging into a ring of NS LDS stages (PRO == 0 only) instead of the register ring
 // waves per SIMD the register budget must allow: 3 where the kernel fits 168 registers without spilling (measured:
 // +10-20 % on the prologue-free variants), 2 for the BN-prologue variants (they spill 35-50 registers at 3)
 // (WM x WN = 4 waves; or 8 waves on a 128x128 tile for launches with too few tiles to give every SIMD two waves)
 #ifndef FRX_OCC4W            // tuning aid: blocks per CU the four-wave tiles are compiled for (0: the table below)
 #define FRX_OCC4W 0
 #endif
-__global__ __launch_bounds__(64 * WM * WN, (NS > 4) ? (WM * WN) / 4 : (KC == 128 || PD > 3) ? 2 : (WM * WN == 8 ? 4 : (FRX_OCC4W ? FRX_OCC4W : ((PRO == 0 && EPI != EPI_BNBWD_OUT && !ADD) ? 3 : 2)))) void k_igemm(ConvArgs a) {
+__global__ __launch_bounds__(64 * WM * WN, (NS > 4) ? (WM * WN) / 4 : (KC == 128 || PD > 3) ? 2 : (WM * WN == 8 ? 4 : (FRX_OCC4W ? FRX_OCC4W : ((PRO == 0 && EPI != EPI_BNBWD_OUT && !ADD) ? 3 : 2)))) void k_igemm(ConvArgs ka) {
   constexpr bool DMA = NS > 0;
   static_assert(!DMA || (PRO == 0 && MODE != MODE_STEM && NS >= 3 && NS <= 8), "LDS-DMA staging: prologue-free launches, 3 to 8 stages");
   constexpr int VEC = TT<T>::VEC, CE = KC / (int)sizeof(T);      // elements per 16-byte load; elements per K-chunk
@@ -305,8 +306,20 @@ __global__ __launch_bounds__(64 * WM * WN, (NS > 4) ? (WM * WN) / 4 : (KC == 128
   constexpr int NTAB = PRO == 2 ? 3 : 2;
 
   FRX_STAMP(0);
+  constexpr bool STATS_ = (EPI == EPI_STATS || EPI == EPI_BNBWD || EPI == EPI_BNBWD_OUT);
+  __shared__ float red[STATS_ ? 2 * WM * BN : 1];             // [2][WM][BN]: the statistics epilogue's cross-wave reduction
+  // PERSISTENT form (template flag PERSIST): the grid may be smaller than the number of tiles (a.nvb "virtual blocks"); block b then runs the
+  // tiles b, b + grid, b + 2 grid, ... one after the other.  (grid / 8) is a multiple of tilesN, so all of a block's tiles
+  // lie in ONE column of tiles: the prologue tables are filled once per block, and the per-channel statistics of its tiles
+  // accumulate in a register per thread and reach memory as ONE burst of atomics per block (bn_tot.h) instead of one per tile.
+  const int tid_ = threadIdx.x;
+  bool first_tile = true;
+  float stat_run = 0.f;            // thread t < 2 BN: running sum of statistic (t / BN) of column (t % BN) over this block's tiles
+  int n0_blk = 0;
+  // (`a` is the argument block: the kernel argument itself, or -- persistent form -- a freshly laundered view of the
+  // kernarg segment, so that every field is loaded where the tile uses it instead of being hoisted out of the tile loop)
+  auto run_tile = [&](const auto& a, const int bid) {
   // XCD-aware tile order: blocks that share an A row-panel (same mt) share an XCD's L2.
-  const int bid = blockIdx.x;
   const int xcd = bid & 7, local = bid >> 3;
   const int mt = (local / a.tilesN) * 8 + xcd, nt = local % a.tilesN;
   if (mt >= a.tilesM) return;
@@ -322,7 +335,9 @@ __global__ __launch_bounds__(64 * WM * WN, (NS > 4) ? (WM * WN) / 4 : (KC == 128
   const bool s2c = MODE == MODE_DGRAD && a.s2c;
   const int m0 = mtl * BM, n0 = nt * BN;
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int tid_l = threadIdx.x;
+  if constexpr (PERSIST) asm volatile("" : "+v"(tid_l));      // (per-thread constants are re-derived per tile, not kept live across the epilogue)
+  const int tid = tid_l, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int chunk = tid & (CPR - 1), srow = tid / CPR;
   // LDS-DMA writes lane-linear, so the XOR swizzle of the LDS image moves to the SOURCE side: the thread whose bytes land in
@@ -393,7 +408,7 @@ __global__ __launch_bounds__(64 * WM * WN, (NS > 4) ? (WM * WN) / 4 : (KC == 128
           if constexpr (PRO == 2) t[2 * VEC] = a.pro_gam[c];
         }
       } else if constexpr (PRO == 1) {      // the producer's replicated totals -> scale / shift (bn_tot.h)
-        const BnTot b = a.in_tot;
+        const BnTot b = bn_tot_copy(a.in_tot);
         bn_tot_foreach<NT>(b.tot, b.R, a.Kc, [&](int c, double sm, double sq) {
           float mean, invstd, sc, sh; double var;
           bn_fwd_consts(sm, sq, b.inv_count, b.gamma[c], b.beta[c], b.eps, mean, invstd, sc, sh, var);
@@ -401,7 +416,7 @@ __global__ __launch_bounds__(64 * WM * WN, (NS > 4) ? (WM * WN) / 4 : (KC == 128
           t[0] = sc; t[VEC] = sh;
         });
       } else {                              // (sum dz, sum dz * xhat) -> alpha / beta / gam
-        const BnTot b = a.pro_tot;
+        const BnTot b = bn_tot_copy(a.pro_tot);
         bn_tot_foreach<NT>(b.tot, b.R, a.Kc, [&](int c, double sa, double sb) {
           float al, be, ga;
           bn_bwd_consts(sa, sb, b.inv_count, b.gamma[c], b.mean[c], b.invstd[c], al, be, ga);
@@ -682,7 +697,7 @@ __global__ __launch_bounds__(64 * WM * WN, (NS > 4) ? (WM * WN) / 4 : (KC == 128
   if constexpr (PD > 1) { if (1 < nk) issue_chunk(1, std::integral_constant<int, 1>{}); }
   if constexpr (PD > 2) { if (2 < nk) issue_chunk(2, std::integral_constant<int, 2>{}); }
   if constexpr (PD > 3) { if (3 < nk) issue_chunk(3, std::integral_constant<int, 3>{}); }
-  fill_pro_tables();
+  if (first_tile) fill_pro_tables();
   commit_chunk(0, std::integral_constant<int, 0>{});
   __syncthreads();
   FRX_STAMP(1);
@@ -859,7 +874,6 @@ __global__ __launch_bounds__(64 * WM * WN, (NS > 4) ? (WM * WN) / 4 : (KC == 128
       for (int r = 0; r < 4; ++r) { vs[j * 4 + r] = csum[j][r]; vq[j * 4 + r] = csq[j][r]; }
     lane16_butterfly<NV, 8>(vs, vq, fr);
     // lane fr now owns value index vi = fr % NV  ->  fragment j = vi>>2, reg r = vi&3
-    __shared__ float red[2 * WM * BN];             // [2][WM][BN]
     if (fr < NV) {
       const int j = fr >> 2, r = fr & 3;
       const int col = wn * WTN + 32 * (j >> 1) + 8 * fq + 4 * (j & 1) + r;
@@ -867,16 +881,41 @@ __global__ __launch_bounds__(64 * WM * WN, (NS > 4) ? (WM * WN) / 4 : (KC == 128
       red[(1 * WM + wm) * BN + col] = vq[0];
     }
     __syncthreads();
-    for (int t = tid; t < 2 * BN; t += NT) {
-      const int which = t / BN, col = t % BN;
+    static_assert(NT >= 2 * BN, "one thread per (statistic, column)");
+    if (tid < 2 * BN) {
+      const int which = tid / BN, col = tid % BN;
       float sum = 0.f;
 #pragma unroll
       for (int w = 0; w < WM; ++w) sum += red[(which * WM + w) * BN + col];
-      if (a.stat_tot)
-        __hip_atomic_fetch_add(a.stat_tot + ((long)(mt % a.stat_R) * 2 + which) * a.Ncol + n0 + col, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      else
-        a.stat_partial[((long)mt * 2 + which) * a.Ncol + n0 + col] = sum;
+      if (a.stat_tot) stat_run += sum;              // (flushed once per block, after its last tile)
+      else a.stat_partial[((long)mt * 2 + which) * a.Ncol + n0 + col] = sum;
     }
+    n0_blk = n0;
+  }
+  first_tile = false;
+  };      // run_tile
+  if constexpr (PERSIST) {
+    // A tile loop makes every block-uniform value of a tile loop-invariant: hipcc hoists them ALL (the ~100 argument words,
+    // 8 buffer descriptors, ...) and the 8-wave tiles, capped at 128 registers, then spill 100+ scalars and 20-30 vector
+    // registers.  So each tile reads its arguments through a pointer to the kernarg segment (ConvArgs is the kernel's only
+    // argument: offset 0) that an empty asm re-defines per tile: nothing derived from it can leave the loop body.
+    typedef const __attribute__((address_space(4))) ConvArgs* kargp_t;
+    for (int vb = blockIdx.x; vb < ka.nvb; vb += gridDim.x) {
+      if (vb != (int)blockIdx.x) __syncthreads();       // the next tile re-uses the LDS stages and `red`
+      kargp_t ap = (kargp_t)__builtin_amdgcn_kernarg_segment_ptr();
+      asm volatile("" : "+s"(ap));
+      run_tile(*ap, vb);
+    }
+  } else {
+    // (one tile per block.  The loop above makes every block-uniform value of a tile loop-invariant: hipcc hoists them all
+    // and the 8-wave tiles, capped at 128 registers, spill 100+ scalars and 20-30 vector registers -- so launches that
+    // do not need the loop do not get it)
+    run_tile(ka, blockIdx.x);
+  }
+  if constexpr (STATS_) {
+    if (ka.stat_tot && tid_ < 2 * BN)      // replica = block index mod R (the XCD id for R = 8: as spread as the row-tile index)
+      __hip_atomic_fetch_add(ka.stat_tot + ((long)(blockIdx.x % ka.stat_R) * 2 + tid_ / BN) * ka.Ncol + n0_blk + tid_ % BN, stat_run,
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 #ifdef FRX_DBG_TIMES
   __builtin_amdgcn_s_waitcnt(0);

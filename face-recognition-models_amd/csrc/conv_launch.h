@@ -74,12 +74,15 @@ int launch_wgrad(hipStream_t st, const WgradArgs& a, int dtype, int bt, int wmod
 int launch_wgrad_grouped(hipStream_t st, int dtype, const WgradArgs* layers, const WgradItem* items, int nitems, bool small_tiles,
                          int* draw_counters);
 
-#define FRX_IGEMM_KN(T_, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, ADD_, KC_, NS_) \
-  hipLaunchKernelGGL((k_igemm<T_, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, ADD_, KC_, 3, NS_>), dim3(grid), dim3(64 * WM_ * WN_), igemm_pro_lds(PRO_, a.Kc), st, a)
+#define FRX_IGEMM_KNP(T_, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, ADD_, KC_, NS_, PERSIST_) \
+  hipLaunchKernelGGL((k_igemm<T_, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, ADD_, KC_, 3, NS_, PERSIST_>), dim3(PERSIST_ ? grid : a.nvb), dim3(64 * WM_ * WN_), igemm_pro_lds(PRO_, a.Kc), st, a)
+#define FRX_IGEMM_KN(T_, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, ADD_, KC_, NS_) FRX_IGEMM_KNP(T_, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, ADD_, KC_, NS_, false)
 #define FRX_IGEMM_K(T_, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, ADD_, KC_) FRX_IGEMM_KN(T_, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, ADD_, KC_, 0)
 #define FRX_IGEMM_LAUNCH64(T_, MODE_, PRO_, EPI_, ADD_)                                                                    \
   do {                                                                                                                     \
-    if (c.bm == 128 && c.bn == 128) FRX_IGEMM_K(T_, 128, 128, 2, 4, MODE_, PRO_, EPI_, ADD_, 64);                           \
+    if (c.bm == 128 && c.bn == 128 && grid < a.nvb && MODE_ == MODE_FWD) FRX_IGEMM_KNP(T_, 128, 128, 2, 4, MODE_, PRO_, EPI_, ADD_, 64, 0, (MODE_ == MODE_FWD)); \
+    else if (c.bm == 128 && c.bn == 64 && grid < a.nvb && MODE_ == MODE_FWD) FRX_IGEMM_KNP(T_, 128, 64, 2, 2, MODE_, PRO_, EPI_, ADD_, 64, 0, (MODE_ == MODE_FWD)); \
+    else if (c.bm == 128 && c.bn == 128) FRX_IGEMM_K(T_, 128, 128, 2, 4, MODE_, PRO_, EPI_, ADD_, 64);                      \
     else if (c.bm == 128 && c.bn == 64) FRX_IGEMM_K(T_, 128, 64, 2, 2, MODE_, PRO_, EPI_, ADD_, 64);                        \
     else FRX_IGEMM_K(T_, 64, 64, 2, 2, MODE_, PRO_, EPI_, ADD_, 64);                                                        \
   } while (0)
