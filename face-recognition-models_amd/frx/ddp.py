@@ -6,18 +6,21 @@ the multi-process tests all go through it.
 The reference has no multi-GPU path at all; semantics chosen here:
   * replicas hold identical weights (broadcast from rank 0 at attach time); each rank owns a shard of the
     global batch;
-  * gradients: SUM all-reduce of the flat fp32 gradient buffer in two phases -- the "upper" ranges
-    (head, fc, layer4, layer3: 94 % of the bytes) as soon as their backward is done, overlapping the
-    backward of layer2 / layer1 / stem, then the "lower" rest; few large messages, because xGMI is
-    point-to-point and a ring collective is bound by one link; the fused SGD applies grad_scale = 1/world;
-    optionally the buckets travel as bf16 (half the bytes on the wire, fp32 accumulation in the update);
+  * gradients: SUM all-reduce of the flat fp32 gradient buffer in three phases -- the "head" ranges (margin head + fc
+    layer: 26 of the 120 MB at 10 575 classes) as soon as the head's and the fc layer's backward are done, i.e. under
+    the backward of layer4; the "upper" ranges (layer4, layer3: 72 %) under the backward of layer2 / layer1 / stem;
+    then the "lower" rest; few large messages, because xGMI is point-to-point and a ring collective is bound by one
+    link; the fused SGD applies grad_scale = 1/world; optionally the buckets travel as bf16 (half the bytes on the
+    wire, fp32 accumulation in the update).  Engines without stage_head / stage_upper_rest (and class-sharded heads,
+    whose head gradient never travels) keep two phases: upper | lower;
   * BatchNorm statistics, AdaFace's norm EMA and VPL's class memory stay per replica (plain-DDP semantics);
   * CurricularFace's EMA uses the GLOBAL mean target cosine (criterion.py:570-573 on the global batch): one
     1-float all-reduce between the two head phases, which is why the forward stage ends at the cosines.
 
-A step is four stages of the engine (engine.FaceEngine.stage_*): forward | upper | lower | update.  Consecutive
-stages with no exchange between them are captured into ONE hipGraph: on one GPU the whole step is a single
-graph; data parallel it is (forward+upper) -> (lower) -> (update), or four graphs for CurricularFace.
+A step is four stages of the engine (engine.FaceEngine.stage_*): forward | upper | lower | update (data parallel: upper
+= head | upper_rest).  Consecutive stages with no exchange between them are captured into ONE hipGraph: on one GPU the
+whole step is a single graph; data parallel it is (forward+head) -> (upper) -> (lower) -> (update), or five graphs for
+CurricularFace.
 
 The engine is duck-typed (tests drive a small CPU model through the very same class over gloo):
   N, device, world (rw), exchange_ty, ty_sum [1], flat_grads, grad_ranges() -> {"upper": [(lo, hi)..], "lower": [..]},
@@ -60,6 +63,12 @@ class DataParallelStep:
         self.on_gpu = torch.device(engine.device).type == "cuda"
         self.use_graph = bool(use_graph) and self.on_gpu
         self.bf16 = bool(bf16_buckets) and self.multi
+        # engines that can finish the head's and the fc layer's gradients early (stage_head / stage_upper_rest) get a bucket
+        # of their own for them (class-sharded heads have no head gradient on the wire: they keep the two-bucket plan)
+        self.head_bucket = (self.multi and hasattr(engine, "stage_head") and hasattr(engine, "stage_upper_rest")
+                            and getattr(engine, "shard", None) is None)
+        if self.head_bucket and hasattr(engine, "set_head_bucket"):
+            engine.set_head_bucket(True)
         self.images = self.labels = None
         if static_inputs is not None:
             self.images, self.labels = static_inputs
@@ -84,8 +93,15 @@ class DataParallelStep:
 
         def upper():
             self._out = e.stage_upper(self.labels)
-        return [("forward", lambda: e.stage_forward(self.images, self.labels), self._comm_ty if (multi and e.exchange_ty) else None),
-                ("upper", upper, self._comm_upper if multi else None),
+
+        def head():
+            self._out = e.stage_head(self.labels)
+        fwd = ("forward", lambda: e.stage_forward(self.images, self.labels), self._comm_ty if (multi and e.exchange_ty) else None)
+        if multi and self.head_bucket:
+            # three gradient messages instead of two: head + fc (final right after the head's backward) | layer3-4 | the rest
+            return [fwd, ("head", head, self._comm_head), ("upper", e.stage_upper_rest, self._comm_upper),
+                    ("lower", e.stage_lower, self._comm_lower), ("update", e.stage_update, None)]
+        return [fwd, ("upper", upper, self._comm_upper if multi else None),
                 ("lower", e.stage_lower, self._comm_lower if multi else None),
                 ("update", e.stage_update, None)]
 
@@ -106,6 +122,9 @@ class DataParallelStep:
 
     def _comm_ty(self):                     # CurricularFace: global sum of the target cosines (criterion.py:570-573)
         dist.all_reduce(self.eng.ty_sum, op=dist.ReduceOp.SUM, group=self.group)
+
+    def _comm_head(self):                   # head + fc gradients: on the wire while layer4 / layer3 run their backward
+        self._pending += self._reduce_ranges("head")
 
     def _comm_upper(self):                  # starts here, runs under the lower backward
         self._pending += self._reduce_ranges("upper")

@@ -498,6 +498,11 @@ class ResNet50Engine:
         cut_w = self.blocks[self.SPLIT_BLOCK].conv1.w_off
         cut_g = self.blocks[self.SPLIT_BLOCK].conv1.g_off
         first_g = self.convs[0].g_off
+        if getattr(self, "head_bucket", False):
+            # the fc layer and the head (26 MB of the 120 at 10 575 classes) are final as soon as the head's backward and
+            # the fc layer's are done: their all-reduce leaves before layer4's backward starts
+            return {"head": [(self.fc_w_off, self.n_params)], "upper": [(cut_w, first_g), (cut_g, self.fc_w_off)],
+                    "lower": [(0, cut_w), (first_g, cut_g)]}
         return {"upper": [(cut_w, first_g), (cut_g, self.n_params)], "lower": [(0, cut_w), (first_g, cut_g)]}
 
     def backward_upper(self, dfeat):
@@ -508,15 +513,23 @@ class ResNet50Engine:
         (dgrad / wgrad of the layer below) read dy = alpha*dz + beta*y + gam on the fly.  Only the 3x3 convs
         (whose 9 taps would re-evaluate the prologue 9x), the downsample BNs and the stem keep the stand-alone
         reduce / apply kernels."""
+        self.backward_fc(dfeat)
+        self.backward_upper_rest()
+
+    def backward_fc(self, dfeat):
+        """the fc layer's backward: its weight / bias gradients are final afterwards (with `head_bucket` its weight gradient
+        is a launch of its own instead of a job of the upper grouped list, so that the bucket can leave early)"""
+        dt, S = self.dtype, self.scratch
+        ops.cast(dt, dfeat, self.dfeat_t, to_f32=False)
+        if not self.grouped_wgrad or getattr(self, "head_bucket", False):   # (grouped: one more job of the upper list --
+            ops.conv_wgrad(self.fc_desc, self.pooled, self.dfeat_t, self.fc_w(self.grads))     # its own launch costs 34 us for 64 tiles)
+        ops.colsum_f32(dfeat, self.fc_b(self.grads))
+        ops.conv_dgrad(self.fc_desc, self.dfeat_t, self.fc_wt, self._like(S[4], self.pooled))
+
+    def backward_upper_rest(self):
         N, dt = self.N, self.dtype
         S = self.scratch
-        # fc
-        ops.cast(dt, dfeat, self.dfeat_t, to_f32=False)
-        if not self.grouped_wgrad:          # (grouped: the fc layer's weight gradient is one more job of the upper list --
-            ops.conv_wgrad(self.fc_desc, self.pooled, self.dfeat_t, self.fc_w(self.grads))     # its own launch cost 34 us for 64 tiles)
-        ops.colsum_f32(dfeat, self.fc_b(self.grads))
         dpool = self._like(S[4], self.pooled)
-        ops.conv_dgrad(self.fc_desc, self.dfeat_t, self.fc_wt, dpool)
         last = self.blocks[-1]
         # last block: its output gradient comes from the average pool, so mask + reduce run stand-alone; the reduce
         # broadcasts the pooled gradient itself (no [N, 4, 4, 2048] tensor, no launch for it)
@@ -679,8 +692,18 @@ class ResNet50Engine:
                     jobs.append(self._wgrad_job(c, x, dz, x_bn=xb, pro_y=c.y, pro_coef=coef))
             jobs.append(self._wgrad_job(b.conv2, b.conv1.y, b.dy2, x_bn=b.conv1))
         groups[2].append(self._wgrad_job(self.stem, self.xin, self.dy_stem))
-        groups[0].append(dict(d=self.fc_desc, x=self.pooled, dy=self.dfeat_t, dw=self.fc_w(self.grads), pro_y=None, pro_coef=None))
+        if not getattr(self, "head_bucket", False):
+            groups[0].append(dict(d=self.fc_desc, x=self.pooled, dy=self.dfeat_t, dw=self.fc_w(self.grads), pro_y=None, pro_coef=None))
         self._wg_groups = [ops.wgrad_group_plan(self.dtype, jobs) for jobs in groups]
+
+    def set_head_bucket(self, on):
+        """data parallel: make the fc layer's gradients final right after the head's backward (grad_ranges()["head"])"""
+        on = bool(on)
+        if on != getattr(self, "head_bucket", False):
+            self.head_bucket = on
+            if self.grouped_wgrad:
+                torch.cuda.synchronize(self.device)
+                self._plan_wgrad_groups()
 
     def _run_wgrad_group(self, which):
         if not self.grouped_wgrad:
@@ -801,6 +824,10 @@ class FaceEngine:
         self.elastic_std = float(elastic_std)
         self.elastic_plus = bool(elastic_plus) and self.kind in ELASTIC_KINDS      # rank-matched margins (criterion.py:1006-1011)
         head_flags = HEAD_FLAG_DEFAULTS.get(self.kind, 0) if head_flags is None else head_flags
+        # bf16 speed mode: the head's three GEMMs on the bf16 matrix cores by operand splitting (hi + lo, three MFMA passes:
+        # logits within 1e-4 of the exact-fp32 GEMM, ~5x its rate); the fp32 parity mode keeps the exact fp32 MFMA chain
+        if dtype == BF16 and os.environ.get("FRX_HEAD_GEMM", "bf16x3") != "f32":
+            head_flags |= 16
         self.head = ops.HeadContext(self.kind, self.N_g, FEATURE_DIM, self.C, self.s, self.m, momentum, device=self.device,
                                     p=self.head_p, flags=head_flags, lambda_g=lambda_g,
                                     class_offset=self.c0 if shard is not None else None)
@@ -963,7 +990,8 @@ class FaceEngine:
         feats = self.net.forward(images)
         ops.head_forward_cos(self.head, feats, self.head_w(), labels, state_t=self.t, ty_sum=self.ty_sum)
 
-    def stage_upper(self, labels):
+    def stage_head(self, labels):
+        """head phase 2 + head backward + the fc layer's backward: the "head" gradient ranges are final afterwards"""
         if self.elastic_plus:
             ops.rank_matched_margins(self.head, self.t, self.margin_scratch)
         out = ops.head_forward_loss(self.head, labels, self.ty_sum, self.N * self.world, state_t=self.t,
@@ -972,8 +1000,19 @@ class FaceEngine:
         self.last = out
         ops.head_backward(self.head, self.net.feats, self.head_w(), labels, state_t=self.t, dx=self.dfeat,
                           dw=self.head_w(self.net.grads), accumulate_dw=False)
-        self.net.backward_upper(self.dfeat)
+        self.net.backward_fc(self.dfeat)
         return out
+
+    def stage_upper_rest(self):
+        self.net.backward_upper_rest()
+
+    def stage_upper(self, labels):
+        out = self.stage_head(labels)
+        self.stage_upper_rest()
+        return out
+
+    def set_head_bucket(self, on):
+        self.net.set_head_bucket(on)
 
     # ---- class-sharded head: the compute between the collectives of frx/ddp.py: sharded_plan
     def shard_stage_backbone(self, images, labels):

@@ -80,6 +80,39 @@ class ToyEngine:
         self.params.sub_(self.lr * self.mom)
 
 
+class ToyEngine3(ToyEngine):
+    """the same model for the three-bucket plan: W2's gradient is written in two halves -- the second one by stage_head
+    (the "head" ranges: final first, on the wire first), the first one by stage_upper_rest"""
+
+    def _mid(self):
+        return self.cut + (self.params.numel() - self.cut) // 2
+
+    def grad_ranges(self):
+        return {"head": [(self._mid(), self.params.numel())], "upper": [(self.cut, self._mid())], "lower": [(0, self.cut)]}
+
+    def stage_head(self, y):
+        self.calls.append("head")
+        if self.exchange_ty:
+            self.t.mul_(0.9).add_(0.1 * self.ty_sum / (self.N * self.world))
+        logits = 8.0 * self.cos * (1.0 + self.t)
+        loss = F.cross_entropy(logits, y)
+        gW2, self.dh = torch.autograd.grad(loss, [self.W2, self.h])
+        self._gW2 = gW2.reshape(-1)
+        m = self._mid() - self.cut
+        self.flat_grads[self._mid():] = self._gW2[m:]
+        return {"loss": loss.detach().reshape(1)}
+
+    def stage_upper_rest(self):
+        self.calls.append("upper_rest")
+        m = self._mid() - self.cut
+        self.flat_grads[self.cut:self._mid()] = self._gW2[:m]
+
+    def stage_upper(self, y):
+        out = self.stage_head(y)
+        self.stage_upper_rest()
+        return out
+
+
 def _data(n, steps, seed=7):
     g = torch.Generator().manual_seed(seed)
     return [(torch.randn(n, ToyEngine.D, generator=g, dtype=torch.float64), torch.randint(0, ToyEngine.C, (n,), generator=g))
@@ -95,22 +128,26 @@ def _single(n_total, steps, exchange):
     return eng, losses
 
 
-def _worker(rank, world, port, q, exchange, bf16):
+def _worker(rank, world, port, q, exchange, bf16, three=False):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from frx import ddp
     n = 8
-    eng = ToyEngine(n, seed=rank, exchange=exchange)          # ranks start DIFFERENT: the broadcast must fix that
+    eng = (ToyEngine3 if three else ToyEngine)(n, seed=rank, exchange=exchange)          # ranks start DIFFERENT: the broadcast must fix that
     st = ddp.DataParallelStep(eng, bf16_buckets=bf16)
     assert eng.world == world and eng.calls == ["after_broadcast"]
-    want = [["forward"], ["upper"], ["lower"], ["update"]] if exchange else [["forward", "upper"], ["lower"], ["update"]]
+    if three:       # head + fc bucket of its own: one more exchange point, one more segment
+        assert st.head_bucket
+        want = [["forward"], ["head"], ["upper"], ["lower"], ["update"]] if exchange else [["forward", "head"], ["upper"], ["lower"], ["update"]]
+    else:
+        want = [["forward"], ["upper"], ["lower"], ["update"]] if exchange else [["forward", "upper"], ["lower"], ["update"]]
     assert st.segments() == want and st.multi and not st.graphed
     losses = []
     for x, y in _data(n * world, 3):
         sl = slice(rank * n, (rank + 1) * n)
         losses.append(st.step(x[sl], y[sl], 0.05)["loss"].item())
-    assert eng.calls[1:6] == ["pre", "forward", "upper", "lower", "update"]
+    assert eng.calls[1:7 if three else 6] == (["pre", "forward", "head", "upper_rest", "lower", "update"] if three else ["pre", "forward", "upper", "lower", "update"])
     # numpy arrays travel by value: a torch tensor in an mp queue is a shared-memory handle that dies with this process,
     # which under load can happen before the parent has mapped it
     q.put((rank, eng.params.numpy().copy(), eng.t.numpy().copy(), losses))
@@ -118,13 +155,14 @@ def _worker(rank, world, port, q, exchange, bf16):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange,bf16", [(True, False), (False, False), (False, True)])
-def test_data_parallel_step_world2_equals_single_process_on_the_concatenated_batch(exchange, bf16):
+@pytest.mark.parametrize("exchange,bf16,three", [(True, False, False), (False, False, False), (False, True, False), (True, False, True),
+                                                 (False, True, True)])
+def test_data_parallel_step_world2_equals_single_process_on_the_concatenated_batch(exchange, bf16, three):
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() * 7 + 3 * exchange + bf16) % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, exchange, bf16)) for r in range(2)]
+    port = 29500 + (os.getpid() * 7 + 3 * exchange + bf16 + 11 * three) % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, exchange, bf16, three)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=180) for _ in procs), key=lambda r: r[0])

