@@ -9,6 +9,7 @@
 // split-bf16 scheme of SURVEY H2 (k_gemm_bf16x3: three bf16 MFMA passes on hi / lo halves of each fp32
 // operand: < 1e-4 on the logits at ~5x the rate), which the bf16 engine selects.
 #include "frx_common.h"
+#include <type_traits>
 
 namespace frx {
 
@@ -203,12 +204,13 @@ __device__ __forceinline__ bf16x8 split_frag(const char* P, int x0, int lane) {
 }
 
 template <bool AMC, bool BNC>
-__global__ __launch_bounds__(256) void k_gemm_bf16x3(GemmArgs g) {
+__global__ __launch_bounds__(256, 2) void k_gemm_bf16x3(GemmArgs g) {
   // per stage: A hi | A lo | B hi | B lo, 4 KB each (64 x 32 bf16)
   __shared__ __attribute__((aligned(16))) char S[2][4][4096];
   const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
   const int kbeg = blockIdx.z * g.ksplit_len;
   const int kend = min(g.K, kbeg + g.ksplit_len);
+  const int nsteps = (kend - kbeg + HBK - 1) / HBK;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave >> 1, wn = wave & 1;
   f32x4 acc[2][2];
@@ -217,29 +219,30 @@ __global__ __launch_bounds__(256) void k_gemm_bf16x3(GemmArgs g) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  float va[2][4], vb[2][4];
-  int ax, ak, bx, bk;
-  auto load_step = [&](int k0) {
+  // Register ring of RD K-steps: the fp32 tile loads run RD - 1 steps ahead of the split + LDS store that consumes them.
+  // (The blocks of these skinny GEMMs -- 256 rows of features against 10^4 .. 10^5 classes, K = 512 -- are few and short:
+  // with the loads one step ahead every step exposed a full memory round trip, 45 us for 2.8 GFLOP.)
+  constexpr int RD = 3;
+  float va[RD][2][4], vb[RD][2][4];
+  int ax = 0, ak = 0, bx = 0, bk = 0;
+  auto load_step = [&](int step, auto slot_tag) {
+    constexpr int sl = decltype(slot_tag)::value;
+    const int k0 = kbeg + step * HBK;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      gemm_load_tile<AMC>(g.A, g.lda, m0, g.M, k0 + 16 * h, kend, g.a_kscale, va[h], ax, ak);
-      gemm_load_tile<BNC>(g.B, g.ldb, n0, g.N, k0 + 16 * h, kend, nullptr, vb[h], bx, bk);
+      gemm_load_tile<AMC>(g.A, g.lda, m0, g.M, k0 + 16 * h, kend, g.a_kscale, va[sl][h], ax, ak);
+      gemm_load_tile<BNC>(g.B, g.ldb, n0, g.N, k0 + 16 * h, kend, nullptr, vb[sl][h], bx, bk);
     }
   };
-  auto store_step = [&](int buf) {
+  auto store_step = [&](int buf, auto slot_tag) {
+    constexpr int sl = decltype(slot_tag)::value;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
-      split_store<AMC>(S[buf][0], va[h], ax, ak, 16 * h);
-      split_store<BNC>(S[buf][2], vb[h], bx, bk, 16 * h);
+      split_store<AMC>(S[buf][0], va[sl][h], ax, ak, 16 * h);
+      split_store<BNC>(S[buf][2], vb[sl][h], bx, bk, 16 * h);
     }
   };
-  load_step(kbeg);
-  store_step(0);
-  __syncthreads();
-  int buf = 0;
-  for (int k0 = kbeg; k0 < kend; k0 += HBK) {
-    const bool more = k0 + HBK < kend;
-    if (more) load_step(k0 + HBK);
+  auto compute = [&](int buf) {
     bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -257,9 +260,27 @@ __global__ __launch_bounds__(256) void k_gemm_bf16x3(GemmArgs g) {
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
       }
-    if (more) store_step(buf ^ 1);
+  };
+  using R0 = std::integral_constant<int, 0>;
+  using R1 = std::integral_constant<int, 1>;
+  using R2 = std::integral_constant<int, 2>;
+  // step s lives in ring slot s % 3 and LDS stage s & 1; one ring step: MFMAs of step s, loads of step s + 3 into the slot
+  // step s just left, split + store of step s + 1, barrier
+  auto ring_step = [&](int sidx, auto cur_tag, auto nxt_tag) {
+    compute(sidx & 1);
+    if (sidx + RD < nsteps) load_step(sidx + RD, cur_tag);
+    if (sidx + 1 < nsteps) store_step((sidx + 1) & 1, nxt_tag);
     __syncthreads();
-    buf ^= 1;
+  };
+  load_step(0, R0{});
+  if (1 < nsteps) load_step(1, R1{});
+  if (2 < nsteps) load_step(2, R2{});
+  store_step(0, R0{});
+  __syncthreads();
+  for (int sidx = 0; sidx < nsteps; sidx += 3) {
+    ring_step(sidx, R0{}, R1{});
+    if (sidx + 1 < nsteps) ring_step(sidx + 1, R1{}, R2{});
+    if (sidx + 2 < nsteps) ring_step(sidx + 2, R2{}, R0{});
   }
   // C/D map of the 16x16 MFMA: col = lane & 15 (n), row = (lane >> 4) * 4 + reg (m)
 #pragma unroll

@@ -826,7 +826,9 @@ class FaceEngine:
         head_flags = HEAD_FLAG_DEFAULTS.get(self.kind, 0) if head_flags is None else head_flags
         # bf16 speed mode: the head's three GEMMs on the bf16 matrix cores by operand splitting (hi + lo, three MFMA passes:
         # logits within 1e-4 of the exact-fp32 GEMM, ~5x its rate); the fp32 parity mode keeps the exact fp32 MFMA chain
-        if dtype == BF16 and os.environ.get("FRX_HEAD_GEMM", "bf16x3") != "f32":
+        # (off by default: measured no faster than the exact kernel -- the head's GEMMs are bound by their tile staging,
+        # not by the matrix pipe: profiles/r03_head_gemm_kernels.txt; FRX_HEAD_GEMM=bf16x3 switches it on)
+        if dtype == BF16 and os.environ.get("FRX_HEAD_GEMM", "f32") == "bf16x3":
             head_flags |= 16
         self.head = ops.HeadContext(self.kind, self.N_g, FEATURE_DIM, self.C, self.s, self.m, momentum, device=self.device,
                                     p=self.head_p, flags=head_flags, lambda_g=lambda_g,

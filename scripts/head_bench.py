@@ -15,7 +15,7 @@ K = int(sys.argv[4]) if len(sys.argv) > 4 else 20
 DEV = torch.device("cuda:0")
 kid = E.HEAD_KINDS[kind]
 s_, m_ = E.HEAD_DEFAULTS[kid]
-FLAGS = E.HEAD_FLAG_DEFAULTS.get(kid, 0) | (0 if os.environ.get("FRX_HEAD_GEMM", "bf16x3") == "f32" else 16)      # bit 4: split-bf16 GEMMs
+FLAGS = E.HEAD_FLAG_DEFAULTS.get(kid, 0) | (16 if os.environ.get("FRX_HEAD_GEMM", "f32") == "bf16x3" else 0)      # bit 4: split-bf16 GEMMs
 ctx = ops.HeadContext(kid, N, 512, C, s_, m_, 0.01, device=DEV, p=E.HEAD_P_DEFAULTS.get(kid, ()), flags=FLAGS)
 g = torch.Generator().manual_seed(0)
 cd = kid in ops.W_CD_KINDS
