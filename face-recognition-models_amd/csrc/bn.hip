@@ -161,7 +161,22 @@ __global__ __launch_bounds__(256) void k_merge_fwd(long rows, int C, const T* __
                                                    const float* bd, T* __restrict__ out,
                                                    uint8_t* __restrict__ mask, BnTot t3, BnTot td) {
   constexpr int V = Vec16<T>::N;
+  const RowWalk w(C, V);
+  const long stride = (long)gridDim.x * w.rpp;
+  const long r_first = (long)blockIdx.x * w.rpp + w.trow;
+  // the first rows' loads are issued BEFORE the constants are derived from the totals: the derivation (R rows per channel,
+  // closing arithmetic, an LDS round trip) then runs under their latency instead of in front of every block
+  Vec16<T> a0[RU], b0[RU];
   if (t3.tot) {               // (block-uniform) constants from the producers' totals instead of finalized arrays
+    if (r_first < rows) {
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        const long rr = r_first + u * stride;
+        const long i = (rr < rows ? rr : r_first) * w.groups + w.tg;
+        a0[u].raw = reinterpret_cast<const uint4*>(y3)[i];
+        b0[u].raw = reinterpret_cast<const uint4*>(idn)[i];
+      }
+    }
     stage_fwd_consts(t3, C, s_bn_dyn, s_bn_dyn + C);
     s3 = s_bn_dyn; b3 = s_bn_dyn + C;
     if (td.tot) {
@@ -170,21 +185,24 @@ __global__ __launch_bounds__(256) void k_merge_fwd(long rows, int C, const T* __
     }
     __syncthreads();
   }
-  const RowWalk w(C, V);
-  const long stride = (long)gridDim.x * w.rpp;
   for (int g0 = 0; g0 < w.groups; g0 += w.gpb) {
     const int grp = g0 + w.tg, c = grp * V;
     float ks[V], kb[V], ds[V], db[V];
     load_consts<V>(s3 + c, ks); load_consts<V>(b3 + c, kb);
     if (sd) { load_consts<V>(sd + c, ds); load_consts<V>(bd + c, db); } else { fill_consts<V>(1.f, ds); fill_consts<V>(0.f, db); }
-    for (long r = (long)blockIdx.x * w.rpp + w.trow; r < rows; r += RU * stride) {
+    for (long r = r_first; r < rows; r += RU * stride) {
       Vec16<T> a[RU], b[RU];
+      if (t3.tot && g0 == 0 && r == r_first) {
 #pragma unroll
-      for (int u = 0; u < RU; ++u) {
-        const long rr = r + u * stride;
-        const long i = (rr < rows ? rr : r) * w.groups + grp;      // clamp: loads stay unconditional
-        a[u].raw = reinterpret_cast<const uint4*>(y3)[i];
-        b[u].raw = reinterpret_cast<const uint4*>(idn)[i];
+        for (int u = 0; u < RU; ++u) { a[u] = a0[u]; b[u] = b0[u]; }
+      } else {
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+          const long rr = r + u * stride;
+          const long i = (rr < rows ? rr : r) * w.groups + grp;      // clamp: loads stay unconditional
+          a[u].raw = reinterpret_cast<const uint4*>(y3)[i];
+          b[u].raw = reinterpret_cast<const uint4*>(idn)[i];
+        }
       }
 #pragma unroll
       for (int u = 0; u < RU; ++u) {
@@ -336,26 +354,41 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(long rows, int C, const T*
                                                       const float* __restrict__ invstd,
                                                       const float* coef, T* __restrict__ dy, BnTot bt) {
   constexpr int V = Vec16<T>::N;
+  const RowWalk w(C, V);
+  const long stride = (long)gridDim.x * w.rpp;
+  const long r_first = (long)blockIdx.x * w.rpp + w.trow;
+  Vec16<T> g0v[RU], y0v[RU];          // (as in k_merge_fwd: the first rows' loads go out before the coefficients are derived)
   if (bt.tot) {
+    if (r_first < rows) {
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        const long rr = r_first + u * stride;
+        const long i = (rr < rows ? rr : r_first) * w.groups + w.tg;
+        g0v[u].raw = reinterpret_cast<const uint4*>(g)[i];
+        y0v[u].raw = reinterpret_cast<const uint4*>(y)[i];
+      }
+    }
     stage_bwd_consts(bt, C, s_bn_dyn);
     coef = s_bn_dyn;
     __syncthreads();
   }
-  const RowWalk w(C, V);
   for (int g0 = 0; g0 < w.groups; g0 += w.gpb) {
     const int grp = g0 + w.tg, c = grp * V;
     float al[V], be[V], ga[V], sc[V], sh[V];
     load_consts<V>(coef + c, al); load_consts<V>(coef + C + c, be); load_consts<V>(coef + 2 * C + c, ga);
     if (relu && !out) { load_consts<V>(scale + c, sc); load_consts<V>(shift + c, sh); } else { fill_consts<V>(1.f, sc); fill_consts<V>(0.f, sh); }
-    const long stride = (long)gridDim.x * w.rpp;
-    for (long r = (long)blockIdx.x * w.rpp + w.trow; r < rows; r += RU * stride) {
+    for (long r = r_first; r < rows; r += RU * stride) {
       Vec16<T> vg[RU], vy[RU], vo[RU];
+      const bool pre = bt.tot && g0 == 0 && r == r_first;
 #pragma unroll
       for (int u = 0; u < RU; ++u) {
         const long rr = r + u * stride;
         const long i = (rr < rows ? rr : r) * w.groups + grp;
-        vg[u].raw = reinterpret_cast<const uint4*>(g)[i];
-        vy[u].raw = reinterpret_cast<const uint4*>(y)[i];
+        if (pre) { vg[u] = g0v[u]; vy[u] = y0v[u]; }
+        else {
+          vg[u].raw = reinterpret_cast<const uint4*>(g)[i];
+          vy[u].raw = reinterpret_cast<const uint4*>(y)[i];
+        }
         if (out) vo[u].raw = reinterpret_cast<const uint4*>(out)[i];
       }
 #pragma unroll

@@ -193,7 +193,10 @@ def test_cosface_full_size_step_configs2_per_gpu_shape():
     b = eng.forward_loss(x, y)
     # (default path: BatchNorm sums by float atomics -- equal to rounding, not bit for bit; the deterministic switch is
     # covered by test_forward_is_bit_reproducible_and_finite)
-    assert ((b["feats"] - f1).norm() / f1.norm()).item() < 5e-2 and abs(b["loss"].item() - l1.item()) < 2e-2 * l1.item()
+    # (measured, scripts/chaos_probe.py / profiles/r03_chaos_probe.txt: the random-init bf16 network amplifies ONE input value
+    # moved by a bf16 ulp to ~0.1 relative L2 in the embeddings, run on the bit-reproducible engine -- that is the scale of
+    # "equal to rounding" for two runs of this network, and what two runs of the totals path differ by)
+    assert ((b["feats"] - f1).norm() / f1.norm()).item() < 0.25 and abs(b["loss"].item() - l1.item()) < 2e-2 * l1.item()
     ref_loss, cos = _head_reference_loss(eng, f1, y, "cosface")
     assert abs(l1.item() - ref_loss) < 1e-3
     z = cos.clone(); z[torch.arange(N, device=DEV), y] -= eng.m
