@@ -9,6 +9,14 @@
 
 namespace frx {
 
+// Patch mode (conv_kernels.h "P3") serves the bf16 3x3 / stride 1 / pad 1 layers: images up to 30 pixels wide (the patch of a
+// 128-pixel tile is 128 + 2 W + 2 rows of the 191 its buffer holds) and an even number of 64-byte channel chunks of the
+// gathered operand.  FRX_CONV3X3=0: off (read per launch).
+static bool p3_geometry(int dtype, int R, int S, int stride, int pad, int Wx, int Kc) {
+  const char* e = getenv("FRX_CONV3X3");
+  return !(e && atoi(e) == 0) && dtype == FRX_BF16 && R == 3 && S == 3 && stride == 1 && pad == 1 && Wx <= 30 && Kc % 64 == 0;
+}
+
 static int launch_igemm(hipStream_t st, ConvArgs a, int dtype) {
   FRX_CHECK_ARG(a.Ncol % 64 == 0, "igemm: output channel count %d must be a multiple of 64", a.Ncol);
   const size_t esz = dtype == FRX_BF16 ? 2 : 4;
@@ -56,6 +64,24 @@ static int launch_igemm(hipStream_t st, ConvArgs a, int dtype) {
   if (a.epi_bnbwd) epi = (a.e_out || a.e_bits) ? EPI_BNBWD_OUT : EPI_BNBWD;
   else if (a.stat_partial || a.stat_tot) epi = EPI_STATS;
   else if (a.out_f32 || a.bias) epi = EPI_FC;
+  // Patch mode: launches with a prologue (forward: BN+ReLU, statistics or plain epilogue; input gradient: BN backward with
+  // the masked-statistics epilogue), no addend.
+  {
+    bool p3 = a.mode != MODE_STEM && !a.s2c && p3_geometry(dtype, a.R, a.S, a.stride, a.pad, a.Wx, a.Kc) && a.Hx == a.Ho && a.Wx == a.Wo &&
+              !a.addend && !a.dy_out && !a.out_f32 && !a.bias;
+    // row tile: 128 pixels; 64 where that would leave CUs without a tile and the columns allow it (the same threshold as
+    // pick_tile's).  Per-tile partial statistics are laid out by frx_conv_stat_rows, i.e. by pick_tile's row tile.
+    const int bn3 = a.Ncol % 128 == 0 ? 128 : 64;
+    const int bm3 = (bn3 == 128 && (long)cdiv(a.M, 128) * (a.Ncol / 128) < 192) ? 64 : 128;
+    p3 = p3 && (!a.stat_partial || c.bm == bm3);
+    p3 = p3 && ((a.mode == MODE_FWD && has_pro && (epi == EPI_STATS || epi == EPI_PLAIN)) || (a.mode == MODE_DGRAD && a.X2 && epi == EPI_BNBWD));
+    if (p3) {
+      a.tilesM = cdiv(a.M, bm3);
+      a.tilesN = a.Ncol / bn3;
+      a.nvb = (int)round_up(a.tilesM, 8) * a.tilesN;
+      return launch_igemm_p3(st, a, epi, bm3, bn3);
+    }
+  }
   if (a.mode == MODE_STEM) return launch_igemm_stem(st, a, dtype, c, grid, epi);
   if (a.mode == MODE_DGRAD)
     return a.X2 ? launch_igemm_dgrad_bn(st, a, dtype, c, grid, epi, a.addend != nullptr)
@@ -109,6 +135,14 @@ extern "C" int frx_conv_tile(const frx_conv_desc* d, int dgrad, int* bm, int* bn
   }
   *bm = c.bm; *bn = c.bn;
   return FRX_OK;
+}
+
+// Diagnostic: 1 if the layer's geometry puts frx_conv_fwd* (dgrad = 0) / frx_conv_dgrad_bn* (dgrad = 1) on the patch-mode
+// 3x3 kernel when the call has a prologue and no addend (and, with per-tile partial statistics, a 128-pixel row tile).
+extern "C" int frx_conv_patch_mode(const frx_conv_desc* d, int dgrad) {
+  if (check_conv(d) != FRX_OK) return -1;
+  if (d->stem) return 0;
+  return p3_geometry(d->dtype, d->R, d->S, d->stride, d->pad, dgrad ? d->Wo : d->Wi, dgrad ? d->Co : d->Ci) ? 1 : 0;
 }
 
 extern "C" int frx_stem_padded_dims(int Hi, int Wi, int* Hp, int* Wp) {

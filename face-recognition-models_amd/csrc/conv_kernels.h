@@ -37,7 +37,8 @@ template <> struct TT<bf16_t> { static constexpr int VEC = 8, CE = 32; };
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ uint4 as_uint4(u32x4_t v) { return make_uint4(v[0], v[1], v[2], v[3]); }
 
-enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_STEM = 2 };
+enum { MODE_FWD = 0, MODE_DGRAD = 1, MODE_STEM = 2,
+       MODE_FWD3 = 3, MODE_DGRAD3 = 4 };   // 3x3, stride 1, pad 1 with the gathered operand staged as a PATCH (k_igemm, "P3")
 // epilogue flavours of k_igemm
 enum { EPI_PLAIN = 0,       // store
        EPI_STATS = 1,       // store + per-channel sum / sum of squares (train-mode BN statistics)
@@ -158,6 +159,12 @@ __device__ __forceinline__ int swz64(int row) { return (0x1320 >> (((row >> 2) &
 
 // Same for [rows][128 B] images (K-chunks of 128 bytes, 8 slots per row, a 256-byte bank row holds two rows): XOR-ing the
 // slot with (row >> 1) & 7 gives the even rows -- and the odd rows -- of every 16-lane service group 8 distinct slots.
+// Patch images (k_igemm P3: [rows][64 B], fragments start at ANY row): XOR-ing the slot with 2 * ((row >> 2) & 1) keeps the
+// 16 consecutive rows of a fragment on 16 distinct slots per service group whatever the first row is -- of the four rows
+// with equal (row & 3), one lies in each quarter of the fragment, the quarters read slots (c, c^1, c^1, c) in a group, and
+// (0, 2, 0, 2) ^ every rotation of (0, 1, 1, 0) is a permutation of 0..3.  (swz64 only holds for row0 = 0 mod 16.)
+__device__ __forceinline__ int pswz(int row) { return (row >> 1) & 2; }
+
 template <int KC> __device__ __forceinline__ int swz_row(int row) {
   if constexpr (KC == 64) return swz64(row);
   else return (row >> 1) & 7;
@@ -282,9 +289,18 @@ template <typename T, int BM, int BN, int WM, int WN, int MODE, int PRO, int EPI
 #ifndef FRX_OCC4W            // tuning aid: blocks per CU the four-wave tiles are compiled for (0: the table below)
 #define FRX_OCC4W 0
 #endif
-__global__ __launch_bounds__(64 * WM * WN, (NS > 4) ? (WM * WN) / 4 : (KC == 128 || PD > 3) ? 2 : (WM * WN == 8 ? 4 : (FRX_OCC4W ? FRX_OCC4W : ((PRO == 0 && EPI != EPI_BNBWD_OUT && !ADD) ? 3 : 2)))) void k_igemm(ConvArgs ka) {
-  constexpr bool DMA = NS > 0;
+__global__ __launch_bounds__(64 * WM * WN, (MODE == MODE_FWD3 || MODE == MODE_DGRAD3) ? (BN == 64 ? 3 : 2) : (NS > 4) ? (WM * WN) / 4 : (KC == 128 || PD > 3) ? 2 : (WM * WN == 8 ? 4 : (FRX_OCC4W ? FRX_OCC4W : ((PRO == 0 && EPI != EPI_BNBWD_OUT && !ADD) ? 3 : 2)))) void k_igemm(ConvArgs ka) {
+  // P3 (MODE_FWD3 / MODE_DGRAD3): 3x3, stride 1, pad 1.  The rows a tile gathers over its nine taps are the CONTIGUOUS pixel
+  // range [m0 - W - 1, m0 + BM + W + 1) of the flattened (n, h, w) axis, so per 64-byte channel chunk that range is staged
+  // ONCE as a patch (LDS-DMA, then the BN prologue in place on the staging thread's own 16-byte pieces) and the nine taps
+  // read their MFMA fragments out of it at per-lane row offsets computed once per tile; a tap that leaves the image points
+  // at a row of zeros.  The prologue's vector-ALU work and the activation traffic drop ~8x against gathering every tap as
+  // a chunk of its own (there: 49 vector instructions per 8 MFMAs, no MFMA / VALU co-execution -- profiles/r03_pmc_3x3_*);
+  // the weights stream through an NS-stage LDS-DMA ring, one 64-byte chunk per tap and step.
+  constexpr bool P3 = (MODE == MODE_FWD3 || MODE == MODE_DGRAD3);
+  constexpr bool DMA = NS > 0 && !P3;
   static_assert(!DMA || (PRO == 0 && MODE != MODE_STEM && NS >= 3 && NS <= 8), "LDS-DMA staging: prologue-free launches, 3 to 8 stages");
+  static_assert(!P3 || (KC == 64 && NS >= 4 && NS <= 8 && !PERSIST && sizeof(T) == 2), "patch mode: bf16, 64-byte chunks, 4 to 8 weight stages");
   constexpr int VEC = TT<T>::VEC, CE = KC / (int)sizeof(T);      // elements per 16-byte load; elements per K-chunk
   constexpr int CPR = KC / 16;                                   // 16-byte slots per row of the LDS image
   constexpr int NT = 64 * WM * WN, RPP = NT / CPR;     // threads; tile rows staged per pass (CPR x 16-byte loads per row)
@@ -294,7 +310,9 @@ __global__ __launch_bounds__(64 * WM * WN, (NS > 4) ? (WM * WN) / 4 : (KC == 128
   static_assert(KC == 64 || KC == 128, "K-chunk of 64 or 128 bytes");
   static_assert(MODE != MODE_STEM || KC == 64, "the stem's rows are 64 bytes per tap row");
   static_assert((WM * WN == 4 || WM * WN == 8) && WTM % 16 == 0 && WTN % 32 == 0 && ALD >= 1 && BLD >= 1, "bad wave tiling");
-  __shared__ __attribute__((aligned(16))) char smem[(DMA ? NS : 2) * STAGE];
+  constexpr int PROWS = BM + 64;            // P3: rows of a patch buffer (the last one is the row of zeros): W <= 30
+  constexpr int PBUF = PROWS * 64;          //     bytes of a patch buffer; [2 (+1: raw y of PRO == 2)] of them, then NS weight stages of BN rows
+  __shared__ __attribute__((aligned(16))) char smem[P3 ? (PRO == 2 ? 3 : 2) * PBUF + NS * BN * 64 : (DMA ? NS : 2) * STAGE];
   static_assert(!DMA || RPP % 16 == 0, "the source-side swizzle must be the same for every row a thread stages");
   // BN scale/shift of the input channels live in LDS: fetching them from global memory at commit
   // time would be the NEWEST vector-memory op and force vmcnt(0), draining the prefetch ring.
@@ -342,7 +360,7 @@ __global__ __launch_bounds__(64 * WM * WN, (NS > 4) ? (WM * WN) / 4 : (KC == 128
   const int chunk = tid & (CPR - 1), srow = tid / CPR;
   // LDS-DMA writes lane-linear, so the XOR swizzle of the LDS image moves to the SOURCE side: the thread whose bytes land in
   // slot `chunk` of its row fetches the logical chunk that belongs there (the same involution the fragment reads apply)
-  const int lchunk = DMA ? (chunk ^ swz_row<KC>(srow)) : chunk;
+  const int lchunk = (DMA || P3) ? (chunk ^ swz_row<KC>(srow)) : chunk;
   const T* __restrict__ X = reinterpret_cast<const T*>(a.X);
   const T* __restrict__ Wp = reinterpret_cast<const T*>(a.W);
   const int Ktot = a.R * a.S * a.Kc;
@@ -465,7 +483,7 @@ __global__ __launch_bounds__(64 * WM * WN, (NS > 4) ? (WM * WN) / 4 : (KC == 128
       avoff[i] = ok ? (unsigned)((off + lchunk * VEC) * (int)sizeof(T)) : OOB;
     }
   };
-  set_tap();
+  if constexpr (!P3) set_tap();
 
   // issue the global loads of chunk kc into ring slot `slot` (no transform yet: nothing waits here)
   auto issue_chunk = [&](int kc, auto slot_tag) {
@@ -552,7 +570,7 @@ __global__ __launch_bounds__(64 * WM * WN, (NS > 4) ? (WM * WN) / 4 : (KC == 128
   // (LDS-DMA path) the two halves of compute_chunk, so that the fragment reads of chunk k + 1 can be in flight under the
   // MFMAs of chunk k: two fragment sets, indexed at compile time only
   constexpr int KS = KC / 64;
-  uint4 pfa[DMA ? 2 : 1][KS][FM], pfb[DMA ? 2 : 1][KS][FN];
+  uint4 pfa[(DMA || P3) ? 2 : 1][KS][FM], pfb[(DMA || P3) ? 2 : 1][KS][FN];
   auto read_frags = [&](int stage, auto par_tag) {
     constexpr int P = decltype(par_tag)::value;
     const char* As = smem + stage * STAGE;
@@ -646,7 +664,150 @@ __global__ __launch_bounds__(64 * WM * WN, (NS > 4) ? (WM * WN) / 4 : (KC == 128
     if constexpr (PD > 3) { if (!GUARDED || k0 + 3 < nk) ring_step(k0 + 3, std::integral_constant<int, 3>{}, guarded_tag); }
   };
   static_assert(PD >= 2 && PD <= 4, "ring depth");
-  if constexpr (DMA) {
+  if constexpr (P3) {
+    constexpr int NPATCH = PRO == 2 ? 3 : 2;            // patch buffers (the third: raw y of the patch being staged)
+    constexpr int NPP = (PROWS * 4) / NT;               // 16-byte pieces per thread and patch
+    constexpr int NPL = NPP * (PRO == 2 ? 2 : 1);       // LDS-DMA instructions per thread and patch
+    constexpr int BST = BN * 64;                        // bytes of a weight stage
+    constexpr int TF = NS - 1 > 5 ? NS - 1 : 5;         // tap step during which the NEXT patch gets its prologue (its pieces have landed from step NS - 1 on)
+    static_assert((PROWS * 4) % NT == 0 && TF <= 7 && BLD * RPP == BN, "patch pieces / weight rows must tile the threads");
+    const int Wd = a.Wx, HWd = a.Hx * a.Wx;
+    const int PR = BM + 2 * Wd + 2;                     // patch rows in use (host: <= PROWS - 1)
+    const int plo = m0 - Wd - 1;                        // pixel of patch row 0
+    const int ncc = a.Kc / CE;                          // channel chunks (host: even)
+    // this thread's pieces of a patch: piece q = u * NT + tid is slot (q & 3) of row (q >> 2), lane-linear for the DMA
+    unsigned pvoff[NPP];
+    int ptab[NPP];
+    bool pfix[NPP];
+#pragma unroll
+    for (int u = 0; u < NPP; ++u) {
+      const int q = u * NT + tid, row = q >> 2, lc = (q & 3) ^ pswz(row), pix = plo + row;
+      const bool ok = row < PR && pix >= 0 && pix < a.M;
+      pvoff[u] = ok ? (unsigned)((pix * a.Kc + lc * VEC) * (int)sizeof(T)) : OOB;
+      ptab[u] = lc * VEC * NTAB;
+      pfix[u] = row < PR;
+    }
+    // fragment row i of this lane at tap t: byte offset inside a patch buffer (the row of zeros when the tap leaves the image)
+    unsigned aaddr[9][FM];
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int lr = wm * WTM + 16 * i + fr, pm = m0 + lr;
+      const bool ok = pm < a.M;
+      const int pp = ok ? pm : 0, n = pp / HWd, rem = pp - n * HWd, h = rem / Wd, w = rem - h * Wd;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int dr = MODE == MODE_FWD3 ? t / 3 - 1 : 1 - t / 3, dc = MODE == MODE_FWD3 ? t % 3 - 1 : 1 - t % 3;
+        const bool valid = ok && (unsigned)(h + dr) < (unsigned)a.Hx && (unsigned)(w + dc) < (unsigned)Wd;
+        const int prow = lr + Wd + 1 + dr * Wd + dc;
+        aaddr[t][i] = valid ? (unsigned)(prow * 64 + ((fq ^ pswz(prow)) << 4)) : (unsigned)((PROWS - 1) * 64 + (fq << 4));
+      }
+    }
+    const u32x4_t rawX2 = raw_rsrc(PRO == 2 ? a.X2 : a.X, a.xbytes), rawX0 = raw_rsrc(a.X, 0), rawW0 = raw_rsrc(a.W, 0);   // (..0: empty descriptors -- every lane out of range, the DMA writes zeros)
+    int b_tap = 0, b_cc = 0;                            // (tap, channel chunk) of the next weight chunk to issue
+    auto dma_b = [&](int stage) {                       // past the last chunk: zeros into a stage nobody reads (keeps the vmcnt arithmetic uniform)
+      const u32x4_t rw = b_cc < ncc ? rawW : rawW0;
+      const int sob = (b_tap * a.Kc + b_cc * CE) * (int)sizeof(T);
+      const unsigned sb = lds0 + NPATCH * PBUF + (unsigned)stage * BST + wrow;
+#pragma unroll
+      for (int i = 0; i < BLD; ++i) dma16(rw, sb + i * RPP * 64, bvoff[i], sob);
+      if (++b_tap == 9) { b_tap = 0; ++b_cc; }
+    };
+    auto dma_patch = [&](int cc, int buf) {
+      const bool live = cc < ncc;
+      const u32x4_t rx = live ? rawX : rawX0, rx2 = live ? rawX2 : rawX0;
+      const int so = cc * CE * (int)sizeof(T);
+#pragma unroll
+      for (int u = 0; u < NPP; ++u) {
+        dma16(rx, lds0 + (unsigned)buf * PBUF + u * NT * 16 + wrow, pvoff[u], so);
+        if constexpr (PRO == 2) dma16(rx2, lds0 + 2 * PBUF + u * NT * 16 + wrow, pvoff[u], so);
+      }
+    };
+    // the prologue, in place, on the pieces this thread staged itself (its own vmcnt covers them: no barrier in between)
+    auto fix_patch = [&](int cc, int buf) {
+      if constexpr (PRO != 0) {
+#pragma unroll
+        for (int u = 0; u < NPP; ++u) {
+          if (pfix[u]) {
+            char* pp = smem + buf * PBUF + (u * NT + tid) * 16;
+            uint4 v = *reinterpret_cast<uint4*>(pp);
+            const float* tb = s_pro + cc * CE * NTAB + ptab[u];
+            if constexpr (PRO == 1) v = bn_relu_vec<T>(v, tb, tb + VEC, a.in_relu);
+            else v = affine2_vec<T>(v, *reinterpret_cast<const uint4*>(smem + 2 * PBUF + (u * NT + tid) * 16), tb, tb + VEC, tb + 2 * VEC);
+            *reinterpret_cast<uint4*>(pp) = v;
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // in LDS before this wave signals the next (raw) barrier
+      }
+    };
+    auto read_p3 = [&](auto tap_tag, auto buf_tag, int stage, auto par_tag) {
+      constexpr int TAP = decltype(tap_tag)::value, BUF = decltype(buf_tag)::value, P = decltype(par_tag)::value;
+      const char* Bs = smem + NPATCH * PBUF + stage * BST;
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int row = wn * WTN + chan_of(j, fr);
+        pfb[P][0][j] = *reinterpret_cast<const uint4*>(Bs + (row * 4 + (fq ^ swz64(row))) * 16);
+      }
+#pragma unroll
+      for (int i = 0; i < FM; ++i) pfa[P][0][i] = *reinterpret_cast<const uint4*>(smem + BUF * PBUF + aaddr[TAP][i]);
+    };
+    int stg = 0;                                        // LDS stage of the current step's weight chunk (step % NS)
+    // Step k = 9 cc + t (channel chunk cc, tap t):  wait until weight chunk k + 1 has landed | barrier | weight chunk
+    // k + NS - 1 into the stage chunk k - 1 just left | t = 0: DMA of patch cc + 1 into the other buffer (last read two
+    // barriers ago) | fragments of step k + 1 | t = TF: prologue on patch cc + 1 (visible after the next barrier, first read
+    // at t = 8) | MFMAs of step k.  Straight-line per pair of chunks: every count below is a compile-time constant.
+    auto step = [&](auto t_tag, auto buf_tag, int cc) {
+      constexpr int t = decltype(t_tag)::value, BUF = decltype(buf_tag)::value, P = (t + BUF) & 1;      // P = k & 1 (9 cc = cc mod 2)
+      const int nxt = stg + 1 == NS ? 0 : stg + 1, prv = stg == 0 ? NS - 1 : stg - 1;
+      // younger than weight chunk k + 1: weight chunks k + 2 .. k + NS - 2 and, for NS - 2 steps after tap 0, the next patch
+#ifndef FRX_P3_ABL          // timing ablations (wrong results): 1 no weight DMA, 2 no fragment reads, 4 no barrier, 8 no MFMA, 16 no patch DMA / prologue
+#define FRX_P3_ABL 0
+#endif
+      wait_vmcnt<(NS - 3) * BLD + ((t >= 1 && t <= NS - 2) ? NPL : 0)>();
+      if constexpr (!(FRX_P3_ABL & 4)) __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);                // (MFMAs touch registers only: without this hipcc pulls the NEXT step's up to right behind their fragment reads)
+      if constexpr (!(FRX_P3_ABL & 1)) dma_b(prv);
+      if constexpr (t == 0 && !(FRX_P3_ABL & 16)) dma_patch(cc + 1, 1 - BUF);
+      if constexpr (!(FRX_P3_ABL & 2)) read_p3(std::integral_constant<int, (t + 1) % 9>{}, std::integral_constant<int, (t == 8 ? 1 - BUF : BUF)>{}, nxt, std::integral_constant<int, 1 - P>{});
+      if constexpr (t == TF && !(FRX_P3_ABL & 16)) fix_patch(cc + 1, 1 - BUF);
+      if constexpr (!(FRX_P3_ABL & 8)) mfma_frags(std::integral_constant<int, P>{});
+      // One wave per SIMD issues one instruction per 4 clocks: the step's ~45 scalar / LDS / address instructions must go
+      // INTO the 16-clock shadows of its 16 MFMAs, not in front of them (measured 700 clocks per step against 256 of MFMA).
+#pragma unroll
+      for (int q = 0; q < FM * FN; ++q) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                      // one MFMA
+        if (q < FM + FN) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);     // one fragment read of the next step
+        __builtin_amdgcn_sched_group_barrier(0x004, 2, 0);                      // scalar bookkeeping of the DMAs
+        __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);                      // address arithmetic / prologue arithmetic
+      }
+      __builtin_amdgcn_sched_barrier(0);                // (this step's MFMAs stay in front of the next barrier, i.e. behind reads issued a step earlier)
+      stg = nxt;
+    };
+    auto chunk9 = [&](auto buf_tag, int cc) {
+      step(std::integral_constant<int, 0>{}, buf_tag, cc); step(std::integral_constant<int, 1>{}, buf_tag, cc);
+      step(std::integral_constant<int, 2>{}, buf_tag, cc); step(std::integral_constant<int, 3>{}, buf_tag, cc);
+      step(std::integral_constant<int, 4>{}, buf_tag, cc); step(std::integral_constant<int, 5>{}, buf_tag, cc);
+      step(std::integral_constant<int, 6>{}, buf_tag, cc); step(std::integral_constant<int, 7>{}, buf_tag, cc);
+      step(std::integral_constant<int, 8>{}, buf_tag, cc);
+    };
+    if (tid < 8) *reinterpret_cast<uint4*>(smem + (tid >> 2) * PBUF + (PROWS - 1) * 64 + (tid & 3) * 16) = make_uint4(0, 0, 0, 0);
+    dma_patch(0, 0);
+#pragma unroll
+    for (int j = 0; j < NS - 1; ++j) dma_b(j);
+    fill_pro_tables();
+    wait_vmcnt<(NS - 1) * BLD>();                       // patch 0 is older than every weight chunk
+    fix_patch(0, 0);
+    wait_vmcnt<(NS - 2) * BLD>();                       // weight chunk 0
+    __syncthreads();
+    read_p3(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0, std::integral_constant<int, 0>{});
+    FRX_STAMP(1);
+    // (the last step still waits, syncs and reads "the fragments of step nk" -- zeros from the empty descriptors: one
+    // barrier too many per tile buys a loop without a tail)
+    for (int cc = 0; cc < ncc; cc += 2) {
+      chunk9(std::integral_constant<int, 0>{}, cc);
+      chunk9(std::integral_constant<int, 1>{}, cc + 1);
+    }
+    wait_vmcnt<0>();
+  } else if constexpr (DMA) {
     // Chunk j lives in LDS stage j % NS.  Software pipeline, one barrier per chunk:
     //   step k:  wait until this wave's part of chunk k + 1 has landed (counted: the younger chunks stay in flight across
     //            the barrier) | barrier: every wave's part of chunk k + 1 has landed, and every wave has consumed the

@@ -70,6 +70,9 @@ int launch_igemm_stem(hipStream_t st, const ConvArgs& a, int dtype, TileCfg c, i
 int launch_igemm_dgrad_plain(hipStream_t st, const ConvArgs& a, int dtype, TileCfg c, int grid, int epi, bool add);
 int launch_igemm_dgrad_bn(hipStream_t st, const ConvArgs& a, int dtype, TileCfg c, int grid, int epi, bool add);
 
+// patch-mode 3x3 (k_igemm MODE_FWD3 / MODE_DGRAD3: bf16, stride 1, pad 1; 128 x bn tile on 2 x 2 waves, or 64 x 128 on 1 x 4)
+int launch_igemm_p3(hipStream_t st, const ConvArgs& a, int epi, int bm, int bn);
+
 int launch_wgrad(hipStream_t st, const WgradArgs& a, int dtype, int bt, int wmode, bool pro, bool ypro, int grid);
 int launch_wgrad_grouped(hipStream_t st, int dtype, const WgradArgs* layers, const WgradItem* items, int nitems, bool small_tiles,
                          int* draw_counters);

@@ -6,7 +6,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libfrx.so")
+_LIB_PATH = os.environ.get("FRX_LIB") or os.path.join(_HERE, "libfrx.so")      # (FRX_LIB: another build of the same library -- scripts/p3_ablate.sh)
 _lib = None
 
 
@@ -88,6 +88,7 @@ _SIGS = {
     "frx_conv_wgrad": (C.c_int, [C.c_int, _P, C.POINTER(ConvDesc), _P, _P, _P, C.c_int, _P, _P]),
     "frx_conv_dgrad_stat_rows": (C.c_int, [C.POINTER(ConvDesc)]),
     "frx_conv_tile": (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "frx_conv_patch_mode": (C.c_int, [C.POINTER(ConvDesc), C.c_int]),
     "frx_wgrad_group_bytes": (C.c_int64, [C.POINTER(WgradJob), C.c_int]),
     "frx_wgrad_group_plan": (C.c_int, [C.c_int, _P, C.POINTER(WgradJob), C.c_int, _P, _P, C.c_int64, C.POINTER(C.c_int),
                                        C.POINTER(C.c_int)]),

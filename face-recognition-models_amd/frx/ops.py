@@ -39,6 +39,14 @@ def _igemm_tile(d, dgrad=False):
     return bm.value, bn.value
 
 
+def conv_patch_mode(d, dgrad=False):
+    """frx_conv_patch_mode: does this layer's geometry take the patch-mode 3x3 kernel (given a prologue and no addend)"""
+    r = _lib.lib().frx_conv_patch_mode(C.byref(d), int(dgrad))
+    if r < 0:
+        raise FrxError("conv descriptor rejected: " + _lib.lib().frx_last_error().decode())
+    return bool(r)
+
+
 def _dt_name(dt):
     return "bf16" if dt == 1 else "f32"
 

@@ -27,7 +27,7 @@ def timeit(fn, reps=10):
     return e0.elapsed_time(e1) * 1e3 / reps
 SH = [(64, 256, 1, 1, 28), (256, 64, 1, 1, 28), (64, 64, 3, 1, 28), (128, 512, 1, 1, 14), (512, 128, 1, 1, 14), (128, 128, 3, 1, 14),
       (256, 1024, 1, 1, 7), (1024, 256, 1, 1, 7), (256, 256, 3, 1, 7), (512, 2048, 1, 1, 4), (2048, 512, 1, 1, 4), (512, 512, 3, 1, 4)]
-for (Ci, Co, k, st, Hi) in SH:
+for (Ci, Co, k, st, Hi) in (SH if __name__ == "__main__" else []):
     d = ops.conv_desc(ops.BF16, N, Hi, Hi, Ci, Co, k, k, st, k // 2)
     x = torch.randn(N, Hi, Hi, Ci, device=DEV).bfloat16(); w = (torch.randn(Co, k, k, Ci, device=DEV) * 0.05).bfloat16()
     y = torch.empty(N, d.Ho, d.Wo, Co, device=DEV, dtype=torch.bfloat16)

@@ -1,0 +1,80 @@
+"""Patch-mode 3x3 (k_igemm P3) against the chunk-per-tap form of the same launch (FRX_CONV3X3=0), same inputs: forward with the
+BN+ReLU prologue + statistics, input gradient with the BN-backward prologue + masked statistics.  The two differ only in the
+order of the fp32 accumulation (channel chunk major vs tap major), so outputs agree to bf16 rounding of equal sums.
+Usage: python scripts/p3_check.py [time]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "face-recognition-models_amd"))
+import torch
+from frx import ops
+DEV = "cuda:0"
+g = torch.Generator().manual_seed(0)
+# (N, H, W, Ci, Co)
+CASES = [(256, 14, 14, 128, 128), (256, 7, 7, 256, 256), (256, 4, 4, 512, 512), (3, 14, 14, 128, 128), (5, 9, 13, 64, 128), (2, 28, 28, 128, 256),
+         (1, 30, 30, 64, 128), (7, 5, 3, 192, 128), (1, 1, 1, 64, 128), (1, 2, 2, 128, 128), (256, 28, 28, 64, 64), (3, 28, 28, 64, 64), (2, 11, 6, 128, 192)]
+bad = 0
+for N, H, W, Ci, Co in CASES:
+    d = ops.conv_desc(ops.BF16, N, H, W, Ci, Co, 3, 3, 1, 1)
+    x = torch.randn(N, H, W, Ci, generator=g).to(DEV).bfloat16()
+    w = (torch.randn(Co, 3, 3, Ci, generator=g) * 0.05).to(DEV).bfloat16()
+    wt = w.permute(3, 1, 2, 0).contiguous()
+    sc, sh = torch.rand(Ci, generator=g).to(DEV) + 0.5, torch.randn(Ci, generator=g).to(DEV) * 0.3
+    dy = torch.randn(N, H, W, Co, generator=g).to(DEV).bfloat16()
+    yy = torch.randn(N, H, W, Co, generator=g).to(DEV).bfloat16()
+    coef = torch.randn(3, Co, generator=g).to(DEV)
+    ey = torch.randn(N, H, W, Ci, generator=g).to(DEV).bfloat16()
+    esc, esh = torch.rand(Ci, generator=g).to(DEV) + 0.5, torch.randn(Ci, generator=g).to(DEV) * 0.1
+    emu, eis = torch.randn(Ci, generator=g).to(DEV) * 0.1, torch.rand(Ci, generator=g).to(DEV) + 0.5
+    res = {}
+    for v in ("0", "1"):
+        os.environ["FRX_CONV3X3"] = v
+        y = torch.full((N, H, W, Co), 7.0, device=DEV, dtype=torch.bfloat16)
+        part = torch.zeros(ops.conv_stat_rows(d) * 2 * Co + 16, device=DEV)
+        ops.conv_fwd(d, x, w, y, in_scale=sc, in_shift=sh, in_relu=True, stat_partial=part)
+        ye = torch.full((N, H, W, Co), 7.0, device=DEV, dtype=torch.bfloat16)
+        ops.conv_fwd(d, x, w, ye, in_scale=sc, in_shift=sh, in_relu=True)
+        dx = torch.full((N, H, W, Ci), 7.0, device=DEV, dtype=torch.bfloat16)
+        part2 = torch.zeros(ops.conv_dgrad_stat_rows(d) * 2 * Ci + 16, device=DEV)
+        ops.conv_dgrad_bn(d, dy, wt, dx, pro_y=yy, pro_coef=coef, epi_y=ey, epi_scale=esc, epi_shift=esh, epi_mean=emu, epi_invstd=eis, epi_partial=part2)
+        torch.cuda.synchronize()
+        rows = ops.conv_stat_rows(d)
+        st = part[: rows * 2 * Co].view(rows, 2, Co).sum(0)
+        rows2 = ops.conv_dgrad_stat_rows(d)
+        st2 = part2[: rows2 * 2 * Ci].view(rows2, 2, Ci).sum(0)
+        res[v] = (y.float(), ye.float(), st, dx.float(), st2)
+    names = ("fwd y", "fwd y (plain epilogue)", "fwd stats", "dgrad dx", "dgrad stats")
+    line = []
+    for nm, a, b in zip(names, res["0"], res["1"]):
+        err = (a - b).abs().max().item()
+        ref = a.abs().max().item() + 1e-30
+        rel = ((a - b).norm() / (a.norm() + 1e-30)).item()
+        ok = rel < 3e-3 and err <= 2e-2 * ref
+        bad += not ok
+        line.append(f"{nm}: max|d| {err:.3e} (max|ref| {ref:.2e}) rel-L2 {rel:.1e}{'' if ok else '  <-- MISMATCH'}")
+    print(f"N={N} {H}x{W} {Ci}->{Co}: " + "; ".join(line), flush=True)
+os.environ.pop("FRX_CONV3X3", None)
+print("MISMATCHES:", bad)
+if len(sys.argv) > 1:
+    for N, H, W, Ci, Co in [(256, 28, 28, 64, 64), (256, 14, 14, 128, 128), (256, 7, 7, 256, 256), (256, 4, 4, 512, 512)]:
+        d = ops.conv_desc(ops.BF16, N, H, W, Ci, Co, 3, 3, 1, 1)
+        x = torch.randn(N, H, W, Ci, generator=g).to(DEV).bfloat16(); w = (torch.randn(Co, 3, 3, Ci, generator=g) * 0.05).to(DEV).bfloat16()
+        wt = w.permute(3, 1, 2, 0).contiguous(); y = torch.empty(N, H, W, Co, device=DEV, dtype=torch.bfloat16)
+        sc, sh = torch.rand(Ci, generator=g).to(DEV) + 0.5, torch.randn(Ci, generator=g).to(DEV) * 0.3
+        dy = torch.randn(N, H, W, Co, generator=g).to(DEV).bfloat16(); yy = torch.randn(N, H, W, Co, generator=g).to(DEV).bfloat16()
+        coef = torch.randn(3, Co, generator=g).to(DEV); ey = torch.randn(N, H, W, Ci, generator=g).to(DEV).bfloat16()
+        esc, esh = torch.rand(Ci, generator=g).to(DEV) + 0.5, torch.randn(Ci, generator=g).to(DEV) * 0.1
+        emu, eis = torch.randn(Ci, generator=g).to(DEV) * 0.1, torch.rand(Ci, generator=g).to(DEV) + 0.5
+        dx = torch.empty_like(x); tot = torch.zeros(8, 2, max(Ci, Co), device=DEV)
+        part = torch.zeros(4096 * 2 * 512, device=DEV)
+        fns = {"fwd": lambda: ops.conv_fwd(d, x, w, y, in_scale=sc, in_shift=sh, in_relu=True),
+               "dgrad": lambda: ops.conv_dgrad_bn(d, dy, wt, dx, pro_y=yy, pro_coef=coef, epi_y=ey, epi_scale=esc, epi_shift=esh, epi_mean=emu, epi_invstd=eis, epi_totals=tot, epi_replicas=8)}
+        for nm, fn in fns.items():
+            best = {}
+            for r in range(9):
+                for v in ("0", "1"):
+                    os.environ["FRX_CONV3X3"] = v
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(); fn(); e1.record(); torch.cuda.synchronize()
+                    best[v] = min(best.get(v, 1e9), e0.elapsed_time(e1) * 1e3)
+            fl = ops.conv_flops(d)
+            print(f"{nm} {Ci}->{Co} @{H}: chunk-per-tap {best['0']:.1f} us ({fl / best['0'] / 1e6:.0f} TF/s)   patch {best['1']:.1f} us ({fl / best['1'] / 1e6:.0f} TF/s)", flush=True)

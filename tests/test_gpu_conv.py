@@ -135,6 +135,136 @@ def test_conv_production_size_vs_aten(shape, tile):
     _conv_case(ops.BF16, shape, 256)
 
 
+# (N, H, W, Ci, Co): the four 3x3 / stride-1 layers at the bench's batch, then ragged cases -- a row tail, H != W, one and
+# two-pixel images (every tap but the centre leaves the image), the widest image a patch buffer holds, 192 = three 64-channel
+# chunks... of the OUTPUT (the forward needs an even number of 64-byte chunks of the input: 64 | Ci)
+PATCH_CASES = [(256, 28, 28, 64, 64), (256, 14, 14, 128, 128), (256, 7, 7, 256, 256), (256, 4, 4, 512, 512), (3, 14, 14, 128, 128),
+               (5, 9, 13, 64, 128), (2, 28, 28, 128, 256), (1, 30, 30, 64, 128), (7, 5, 3, 192, 128), (1, 1, 1, 64, 128), (1, 2, 2, 128, 64),
+               (2, 11, 6, 128, 192)]
+
+
+@pytest.mark.parametrize("case", PATCH_CASES, ids=lambda c: "n%dh%dw%d_%dto%d" % c)
+def test_patch_3x3_forward_vs_aten(case):
+    """the patch-mode 3x3 kernel (k_igemm P3: BN+ReLU prologue applied once per staged patch, nine taps read at per-lane row
+    offsets, weights through an LDS-DMA ring) against ATen CPU fp32 -- plain epilogue, statistics as replicated totals,
+    and (where the layer's partial-rows tile is the patch tile) statistics as partial rows"""
+    from frx import ops
+    N, H, W, Ci, Co = case
+    d = ops.conv_desc(ops.BF16, N, H, W, Ci, Co, 3, 3, 1, 1)
+    assert ops.conv_patch_mode(d), "geometry no longer eligible for the kernel this test was written for"
+    x = _mk(1, N, H, W, Ci, seed=1)
+    w = _mk(1, Co, 3, 3, Ci, scale=(Ci * 9) ** -0.5, seed=2)
+    sc = (torch.rand(Ci, generator=torch.Generator().manual_seed(3)) + 0.5)
+    sc[::3] *= -1
+    sh = torch.randn(Ci, generator=torch.Generator().manual_seed(4)) * 0.3
+    xd, wd, scd, shd = x.to(DEV), w.to(DEV), sc.to(DEV), sh.to(DEV)
+    xin = torch.relu(x.float() * sc + sh).to(x.dtype).float()
+    ref = F.conv2d(xin.permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), stride=1, padding=1).permute(0, 2, 3, 1).contiguous()
+    y = torch.full((N, H, W, Co), float("nan"), dtype=x.dtype, device=DEV)
+    ops.conv_fwd(d, xd, wd, y, in_scale=scd, in_shift=shd, in_relu=True)
+    _close(y, ref, 1, "patch fwd, plain epilogue")
+    # statistics into R replicated rows (the training step's form); the prologue constants given as arrays here
+    R = 4
+    tot = torch.zeros(R, 2, Co, device=DEV)
+    y2 = torch.full_like(y, float("nan"))
+    g = torch.Generator().manual_seed(5)
+    gamma, beta = (torch.rand(Ci, generator=g) + 0.5).to(DEV), (torch.randn(Ci, generator=g) * 0.3).to(DEV)
+    count = float(N * H * W)
+    tin = torch.zeros(2, 2, Ci, device=DEV)
+    xs = x.float()
+    tin[0, 0] = xs.sum((0, 1, 2)).to(DEV) * 0.25; tin[1, 0] = xs.sum((0, 1, 2)).to(DEV) * 0.75
+    tin[0, 1] = (xs * xs).sum((0, 1, 2)).to(DEV) * 0.5; tin[1, 1] = (xs * xs).sum((0, 1, 2)).to(DEV) * 0.5
+    ops.conv_fwd_tot(d, xd, wd, y2, in_bn=ops.bn_tot(tin, 2, count, gamma, beta=beta), stat_totals=tot, stat_replicas=R)
+    mean = xs.mean((0, 1, 2)); var = (xs * xs).mean((0, 1, 2)) - mean * mean
+    sc2 = gamma.cpu() / torch.sqrt(var + 1e-5); sh2 = beta.cpu() - mean * sc2
+    xin2 = torch.relu(xs * sc2 + sh2).to(x.dtype).float()
+    ref2 = F.conv2d(xin2.permute(0, 3, 1, 2), w.float().permute(0, 3, 1, 2), stride=1, padding=1).permute(0, 2, 3, 1).contiguous()
+    _close(y2, ref2, 1, "patch fwd, constants from totals")
+    yq = y2.float().cpu()
+    _close(tot[:, 0].sum(0), yq.sum((0, 1, 2)), 0, "totals: sum")
+    _close(tot[:, 1].sum(0), (yq * yq).sum((0, 1, 2)), 0, "totals: sum of squares")
+    if ops._igemm_tile(d)[0] == 128:
+        rows = ops.conv_stat_rows(d)
+        part = torch.zeros(rows, 2, Co, device=DEV)
+        y3 = torch.full_like(y, float("nan"))
+        ops.conv_fwd(d, xd, wd, y3, in_scale=scd, in_shift=shd, in_relu=True, stat_partial=part)
+        assert torch.equal(y3, y), "the epilogue flavour must not change the outputs"
+        yq = y3.float().cpu()
+        _close(part[:, 0].sum(0), yq.sum((0, 1, 2)), 0, "partial rows: sum")
+        _close(part[:, 1].sum(0), (yq * yq).sum((0, 1, 2)), 0, "partial rows: sum of squares")
+
+
+@pytest.mark.parametrize("case", PATCH_CASES, ids=lambda c: "n%dh%dw%d_%dto%d" % c)
+def test_patch_3x3_input_gradient_vs_aten(case):
+    """the patch-mode input gradient: dy = alpha dz + beta y + gam (BN backward of this conv's output) staged once per patch,
+    dx = conv^T(dy) masked by the ReLU of the BatchNorm below, dz and the two masked statistics -- against the same
+    composition in fp32 on the CPU (ATen's conv2d_input)"""
+    from frx import ops
+    N, H, W, Ci, Co = case
+    d = ops.conv_desc(ops.BF16, N, H, W, Ci, Co, 3, 3, 1, 1)
+    if Co % 64:
+        pytest.skip("the input gradient gathers Co channels: needs 64 | Co")
+    assert ops.conv_patch_mode(d, True)
+    T = torch.bfloat16
+    dz, yraw = _mk(1, N, H, W, Co, seed=1), _mk(1, N, H, W, Co, seed=2)
+    g = torch.Generator().manual_seed(3)
+    coef = torch.cat([torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g) * 0.2, torch.randn(Co, generator=g) * 0.1])
+    w = _mk(1, Co, 3, 3, Ci, scale=(Co * 9) ** -0.5, seed=4)
+    ey = _mk(1, N, H, W, Ci, seed=7)
+    esc = torch.rand(Ci, generator=g) + 0.5
+    esc[::4] *= -1
+    esh = torch.randn(Ci, generator=g) * 0.3
+    emu, eis = torch.randn(Ci, generator=g) * 0.2, torch.rand(Ci, generator=g) + 0.5
+    dy = (coef[:Co] * dz.float() + coef[Co:2 * Co] * yraw.float() + coef[2 * Co:]).to(T).float()
+    dx = torch.nn.grad.conv2d_input((N, Ci, H, W), w.float().permute(0, 3, 1, 2), dy.permute(0, 3, 1, 2), stride=1, padding=1).permute(0, 2, 3, 1)
+    mask = (ey.float() * esc + esh) > 0
+    ref = torch.where(mask, dx, torch.zeros_like(dx))
+    R = 8
+    tot = torch.zeros(R, 2, Ci, device=DEV)
+    out = torch.full((N, H, W, Ci), float("nan"), dtype=T, device=DEV)
+    wt = w.permute(3, 1, 2, 0).contiguous().to(DEV)
+    dv = lambda t: t.to(DEV)
+    ops.conv_dgrad_bn(d, dv(dz), wt, out, pro_y=dv(yraw), pro_coef=dv(coef), epi_y=dv(ey), epi_scale=dv(esc), epi_shift=dv(esh),
+                      epi_mean=dv(emu), epi_invstd=dv(eis), epi_totals=tot, epi_replicas=R)
+    _close(out, ref, 1, "patch dgrad: dz")
+    # a masked element whose pre-activation is within rounding of 0 may flip: compare the statistics on the kernel's own dz
+    oq = out.float().cpu()
+    xhat = (ey.float() - emu) * eis
+    _close(tot[:, 0].sum(0), oq.sum((0, 1, 2)), 0, "patch dgrad: sum dz")
+    s2 = (oq * xhat).sum((0, 1, 2))
+    assert (tot[:, 1].sum(0).cpu() - s2).abs().max().item() <= 2e-3 * (s2.abs().max().item() + 1e-6) + 1e-4
+    if ops._igemm_tile(d, True)[0] == 128:
+        rows = ops.conv_dgrad_stat_rows(d)
+        part = torch.zeros(rows, 2, Ci, device=DEV)
+        out2 = torch.full_like(out, float("nan"))
+        ops.conv_dgrad_bn(d, dv(dz), wt, out2, pro_y=dv(yraw), pro_coef=dv(coef), epi_y=dv(ey), epi_scale=dv(esc), epi_shift=dv(esh),
+                          epi_mean=dv(emu), epi_invstd=dv(eis), epi_partial=part)
+        assert torch.equal(out2, out)
+        _close(part[:, 0].sum(0), oq.sum((0, 1, 2)), 0, "patch dgrad: partial rows, sum dz")
+
+
+def test_patch_3x3_matches_chunk_per_tap(monkeypatch):
+    """the two main loops of the same launch (FRX_CONV3X3=0: one gathered K-chunk per tap) differ only in the order of the
+    fp32 accumulation: outputs agree to bf16 rounding of equal sums, statistics to 1e-5"""
+    from frx import ops
+    N, H, W, Ci, Co = 64, 14, 14, 128, 128
+    d = ops.conv_desc(ops.BF16, N, H, W, Ci, Co, 3, 3, 1, 1)
+    x, w = _mk(1, N, H, W, Ci, seed=1).to(DEV), _mk(1, Co, 3, 3, Ci, scale=(Ci * 9) ** -0.5, seed=2).to(DEV)
+    g = torch.Generator().manual_seed(3)
+    sc, sh = (torch.rand(Ci, generator=g) + 0.5).to(DEV), (torch.randn(Ci, generator=g) * 0.3).to(DEV)
+    res = {}
+    for v in ("0", "1"):
+        monkeypatch.setenv("FRX_CONV3X3", v)
+        y = torch.empty(N, H, W, Co, dtype=torch.bfloat16, device=DEV)
+        rows = ops.conv_stat_rows(d)
+        part = torch.zeros(rows, 2, Co, device=DEV)
+        ops.conv_fwd(d, x, w, y, in_scale=sc, in_shift=sh, in_relu=True, stat_partial=part)
+        res[v] = (y.float(), part.sum(0))
+    rel = ((res["1"][0] - res["0"][0]).norm() / res["0"][0].norm()).item()
+    assert rel < 2e-4, rel
+    assert ((res["1"][1] - res["0"][1]).abs().max() / res["0"][1].abs().max()).item() < 1e-5
+
+
 @pytest.mark.parametrize("shape", [(1024, 256, 1, 1, 7), (256, 256, 3, 1, 7), (256, 64, 1, 1, 28), (256, 256, 3, 2, 14)], ids=_sid)
 @pytest.mark.parametrize("merge_mask", [False, True], ids=["relu_bn_mask", "merge_mask"])
 def test_fused_bn_backward_production_size(shape, merge_mask):
