@@ -17,6 +17,12 @@ static bool p3_geometry(int dtype, int R, int S, int stride, int pad, int Wx, in
   return !(e && atoi(e) == 0) && dtype == FRX_BF16 && R == 3 && S == 3 && stride == 1 && pad == 1 && Wx <= 30 && Kc % 64 == 0;
 }
 
+// its tile: 128 pixels x (128 | 64) columns; 64 x 128 where 128-pixel tiles would leave CUs without one (pick_tile's threshold)
+static void p3_tile(long M, int Ncol, int* bm, int* bn) {
+  *bn = Ncol % 128 == 0 ? 128 : 64;
+  *bm = (*bn == 128 && (long)cdiv(M, 128) * (Ncol / 128) < 192) ? 64 : 128;
+}
+
 static int launch_igemm(hipStream_t st, ConvArgs a, int dtype) {
   FRX_CHECK_ARG(a.Ncol % 64 == 0, "igemm: output channel count %d must be a multiple of 64", a.Ncol);
   const size_t esz = dtype == FRX_BF16 ? 2 : 4;
@@ -68,11 +74,11 @@ static int launch_igemm(hipStream_t st, ConvArgs a, int dtype) {
   // the masked-statistics epilogue), no addend.
   {
     bool p3 = a.mode != MODE_STEM && !a.s2c && p3_geometry(dtype, a.R, a.S, a.stride, a.pad, a.Wx, a.Kc) && a.Hx == a.Ho && a.Wx == a.Wo &&
-              !a.addend && !a.dy_out && !a.out_f32 && !a.bias;
+              !a.addend && !a.out_f32 && !a.bias;
     // row tile: 128 pixels; 64 where that would leave CUs without a tile and the columns allow it (the same threshold as
     // pick_tile's).  Per-tile partial statistics are laid out by frx_conv_stat_rows, i.e. by pick_tile's row tile.
-    const int bn3 = a.Ncol % 128 == 0 ? 128 : 64;
-    const int bm3 = (bn3 == 128 && (long)cdiv(a.M, 128) * (a.Ncol / 128) < 192) ? 64 : 128;
+    int bm3, bn3;
+    p3_tile(a.M, a.Ncol, &bm3, &bn3);
     p3 = p3 && (!a.stat_partial || c.bm == bm3);
     p3 = p3 && ((a.mode == MODE_FWD && has_pro && (epi == EPI_STATS || epi == EPI_PLAIN)) || (a.mode == MODE_DGRAD && a.X2 && epi == EPI_BNBWD));
     if (p3) {
@@ -81,6 +87,9 @@ static int launch_igemm(hipStream_t st, ConvArgs a, int dtype) {
       a.nvb = (int)round_up(a.tilesM, 8) * a.tilesN;
       return launch_igemm_p3(st, a, epi, bm3, bn3);
     }
+    FRX_CHECK_ARG(!(a.dy_out && (a.R != 1 || a.S != 1)),
+                  "conv_dgrad_bn: pro_dy_out on a 3x3 needs the patch-mode launch (BN-backward prologue, masked-statistics epilogue, no "
+                  "addend; partial-statistics rows only where frx_conv_tile's row tile is frx_conv_patch_mode's)");
   }
   if (a.mode == MODE_STEM) return launch_igemm_stem(st, a, dtype, c, grid, epi);
   if (a.mode == MODE_DGRAD)
@@ -137,12 +146,15 @@ extern "C" int frx_conv_tile(const frx_conv_desc* d, int dgrad, int* bm, int* bn
   return FRX_OK;
 }
 
-// Diagnostic: 1 if the layer's geometry puts frx_conv_fwd* (dgrad = 0) / frx_conv_dgrad_bn* (dgrad = 1) on the patch-mode
+// Diagnostic: the row tile (128 or 64 pixels; 0: not eligible) if the layer's geometry puts frx_conv_fwd* (dgrad = 0) / frx_conv_dgrad_bn* (dgrad = 1) on the patch-mode
 // 3x3 kernel when the call has a prologue and no addend (and, with per-tile partial statistics, a 128-pixel row tile).
 extern "C" int frx_conv_patch_mode(const frx_conv_desc* d, int dgrad) {
   if (check_conv(d) != FRX_OK) return -1;
   if (d->stem) return 0;
-  return p3_geometry(d->dtype, d->R, d->S, d->stride, d->pad, dgrad ? d->Wo : d->Wi, dgrad ? d->Co : d->Ci) ? 1 : 0;
+  if (!p3_geometry(d->dtype, d->R, d->S, d->stride, d->pad, dgrad ? d->Wo : d->Wi, dgrad ? d->Co : d->Ci)) return 0;
+  int bm, bn;
+  p3_tile((long)d->N * d->Ho * d->Wo, dgrad ? d->Ci : d->Co, &bm, &bn);
+  return bm;
 }
 
 extern "C" int frx_stem_padded_dims(int Hi, int Wi, int* Hp, int* Wp) {
@@ -239,7 +251,8 @@ static int dgrad_impl(int device, frx_stream_t stream, const frx_conv_desc* d, c
     }
     if (f->pro_dy_out) {
       FRX_CHECK_ARG(f->pro_y != nullptr, "conv_dgrad_bn: pro_dy_out needs the BN prologue (pro_y)");
-      FRX_CHECK_ARG(d->R == 1 && d->S == 1, "conv_dgrad_bn: pro_dy_out is for 1x1 convs (each dy element is gathered once)");
+      FRX_CHECK_ARG((d->R == 1 && d->S == 1) || p3_geometry(d->dtype, d->R, d->S, d->stride, d->pad, d->Wo, d->Co),
+                    "conv_dgrad_bn: pro_dy_out is for 1x1 convs and the patch-mode 3x3 (each dy element is transformed once)");
       a.dy_out = f->pro_dy_out;
     }
     if (f->epi_y) {

@@ -670,13 +670,13 @@ __global__ __launch_bounds__(64 * WM * WN, (MODE == MODE_FWD3 || MODE == MODE_DG
     constexpr int NPL = NPP * (PRO == 2 ? 2 : 1);       // LDS-DMA instructions per thread and patch
     constexpr int BST = BN * 64;                        // bytes of a weight stage
     constexpr int TF = NS - 1 > 5 ? NS - 1 : 5;         // tap step during which the NEXT patch gets its prologue (its pieces have landed from step NS - 1 on)
-    static_assert((PROWS * 4) % NT == 0 && TF <= 7 && BLD * RPP == BN, "patch pieces / weight rows must tile the threads");
+    static_assert((PROWS * 4) % NT == 0 && TF <= 7 && TF + NS - 2 <= 8 + TF && BLD * RPP == BN, "patch pieces / weight rows must tile the threads");
     const int Wd = a.Wx, HWd = a.Hx * a.Wx;
     const int PR = BM + 2 * Wd + 2;                     // patch rows in use (host: <= PROWS - 1)
     const int plo = m0 - Wd - 1;                        // pixel of patch row 0
     const int ncc = a.Kc / CE;                          // channel chunks (host: even)
     // this thread's pieces of a patch: piece q = u * NT + tid is slot (q & 3) of row (q >> 2), lane-linear for the DMA
-    unsigned pvoff[NPP];
+    unsigned pvoff[NPP], pstoff[NPP];
     int ptab[NPP];
     bool pfix[NPP];
 #pragma unroll
@@ -686,7 +686,12 @@ __global__ __launch_bounds__(64 * WM * WN, (MODE == MODE_FWD3 || MODE == MODE_DG
       pvoff[u] = ok ? (unsigned)((pix * a.Kc + lc * VEC) * (int)sizeof(T)) : OOB;
       ptab[u] = lc * VEC * NTAB;
       pfix[u] = row < PR;
+      // PRO == 2 side output (dy = the transformed operand, for the weight gradient): every pixel is the OWN row of exactly
+      // one row tile (patch rows W + 1 .. W + BM); the first column of tiles stores them (rsrcDy is empty elsewhere)
+      pstoff[u] = (ok && row > Wd && row <= Wd + BM) ? pvoff[u] : OOB;
     }
+    constexpr int NST = PRO == 2 ? NPP : 0;             // stores per thread and patch: issued UNCONDITIONALLY (they count in vmcnt)
+    const __amdgpu_buffer_rsrc_t rsrcDy0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.X), 0, 0u, 0x00020000);
     // fragment row i of this lane at tap t: byte offset inside a patch buffer (the row of zeros when the tap leaves the image)
     unsigned aaddr[9][FM];
 #pragma unroll
@@ -725,15 +730,21 @@ __global__ __launch_bounds__(64 * WM * WN, (MODE == MODE_FWD3 || MODE == MODE_DG
     // the prologue, in place, on the pieces this thread staged itself (its own vmcnt covers them: no barrier in between)
     auto fix_patch = [&](int cc, int buf) {
       if constexpr (PRO != 0) {
+        const __amdgpu_buffer_rsrc_t rdy = cc < ncc ? rsrcDy : rsrcDy0;      // (the step after the last chunk works on zeros: nothing of it may be stored)
 #pragma unroll
         for (int u = 0; u < NPP; ++u) {
+          uint4 v = make_uint4(0, 0, 0, 0);
           if (pfix[u]) {
             char* pp = smem + buf * PBUF + (u * NT + tid) * 16;
-            uint4 v = *reinterpret_cast<uint4*>(pp);
+            v = *reinterpret_cast<uint4*>(pp);
             const float* tb = s_pro + cc * CE * NTAB + ptab[u];
             if constexpr (PRO == 1) v = bn_relu_vec<T>(v, tb, tb + VEC, a.in_relu);
             else v = affine2_vec<T>(v, *reinterpret_cast<const uint4*>(smem + 2 * PBUF + (u * NT + tid) * 16), tb, tb + VEC, tb + 2 * VEC);
             *reinterpret_cast<uint4*>(pp) = v;
+          }
+          if constexpr (PRO == 2) {      // (soffset stays the literal 0: see the note on stores in the epilogue)
+            u32x4_t sv; sv[0] = v.x; sv[1] = v.y; sv[2] = v.z; sv[3] = v.w;
+            __builtin_amdgcn_raw_buffer_store_b128(sv, rdy, pstoff[u] + (unsigned)(cc * CE * (int)sizeof(T)), 0, 0);
           }
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // in LDS before this wave signals the next (raw) barrier
@@ -755,14 +766,19 @@ __global__ __launch_bounds__(64 * WM * WN, (MODE == MODE_FWD3 || MODE == MODE_DG
     // k + NS - 1 into the stage chunk k - 1 just left | t = 0: DMA of patch cc + 1 into the other buffer (last read two
     // barriers ago) | fragments of step k + 1 | t = TF: prologue on patch cc + 1 (visible after the next barrier, first read
     // at t = 8) | MFMAs of step k.  Straight-line per pair of chunks: every count below is a compile-time constant.
-    auto step = [&](auto t_tag, auto buf_tag, int cc) {
+    auto step = [&](auto t_tag, auto buf_tag, auto first_tag, int cc) {
       constexpr int t = decltype(t_tag)::value, BUF = decltype(buf_tag)::value, P = (t + BUF) & 1;      // P = k & 1 (9 cc = cc mod 2)
+      constexpr bool FIRST = decltype(first_tag)::value;                                               // chunk 0 of the tile
       const int nxt = stg + 1 == NS ? 0 : stg + 1, prv = stg == 0 ? NS - 1 : stg - 1;
-      // younger than weight chunk k + 1: weight chunks k + 2 .. k + NS - 2 and, for NS - 2 steps after tap 0, the next patch
+      // younger than weight chunk k + 1 (vmcnt counts loads, stores and LDS-DMA together, in issue order): weight chunks
+      // k + 2 .. k + NS - 2; for NS - 2 steps after tap 0 the next patch; and the side-output stores of a prologue pass for the
+      // NS - 2 steps that follow it -- this chunk's (issued at t = TF), the previous chunk's where that window wraps, and in
+      // chunk 0 those of the pass in front of the loop (they sit between weight chunks NS - 2 and NS - 1)
+      constexpr bool ST = (t > TF && t <= TF + NS - 2) || (!FIRST && t + 9 <= TF + NS - 2) || (FIRST && t <= NS - 3);
 #ifndef FRX_P3_ABL          // timing ablations (wrong results): 1 no weight DMA, 2 no fragment reads, 4 no barrier, 8 no MFMA, 16 no patch DMA / prologue
 #define FRX_P3_ABL 0
 #endif
-      wait_vmcnt<(NS - 3) * BLD + ((t >= 1 && t <= NS - 2) ? NPL : 0)>();
+      wait_vmcnt<(NS - 3) * BLD + ((t >= 1 && t <= NS - 2) ? NPL : 0) + (ST ? NST : 0)>();
       if constexpr (!(FRX_P3_ABL & 4)) __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);                // (MFMAs touch registers only: without this hipcc pulls the NEXT step's up to right behind their fragment reads)
       if constexpr (!(FRX_P3_ABL & 1)) dma_b(prv);
@@ -782,12 +798,12 @@ __global__ __launch_bounds__(64 * WM * WN, (MODE == MODE_FWD3 || MODE == MODE_DG
       __builtin_amdgcn_sched_barrier(0);                // (this step's MFMAs stay in front of the next barrier, i.e. behind reads issued a step earlier)
       stg = nxt;
     };
-    auto chunk9 = [&](auto buf_tag, int cc) {
-      step(std::integral_constant<int, 0>{}, buf_tag, cc); step(std::integral_constant<int, 1>{}, buf_tag, cc);
-      step(std::integral_constant<int, 2>{}, buf_tag, cc); step(std::integral_constant<int, 3>{}, buf_tag, cc);
-      step(std::integral_constant<int, 4>{}, buf_tag, cc); step(std::integral_constant<int, 5>{}, buf_tag, cc);
-      step(std::integral_constant<int, 6>{}, buf_tag, cc); step(std::integral_constant<int, 7>{}, buf_tag, cc);
-      step(std::integral_constant<int, 8>{}, buf_tag, cc);
+    auto chunk9 = [&](auto buf_tag, auto first_tag, int cc) {
+      step(std::integral_constant<int, 0>{}, buf_tag, first_tag, cc); step(std::integral_constant<int, 1>{}, buf_tag, first_tag, cc);
+      step(std::integral_constant<int, 2>{}, buf_tag, first_tag, cc); step(std::integral_constant<int, 3>{}, buf_tag, first_tag, cc);
+      step(std::integral_constant<int, 4>{}, buf_tag, first_tag, cc); step(std::integral_constant<int, 5>{}, buf_tag, first_tag, cc);
+      step(std::integral_constant<int, 6>{}, buf_tag, first_tag, cc); step(std::integral_constant<int, 7>{}, buf_tag, first_tag, cc);
+      step(std::integral_constant<int, 8>{}, buf_tag, first_tag, cc);
     };
     if (tid < 8) *reinterpret_cast<uint4*>(smem + (tid >> 2) * PBUF + (PROWS - 1) * 64 + (tid & 3) * 16) = make_uint4(0, 0, 0, 0);
     dma_patch(0, 0);
@@ -796,15 +812,19 @@ __global__ __launch_bounds__(64 * WM * WN, (MODE == MODE_FWD3 || MODE == MODE_DG
     fill_pro_tables();
     wait_vmcnt<(NS - 1) * BLD>();                       // patch 0 is older than every weight chunk
     fix_patch(0, 0);
-    wait_vmcnt<(NS - 2) * BLD>();                       // weight chunk 0
+    wait_vmcnt<(NS - 2) * BLD + NST>();                 // weight chunk 0 (younger: the other chunks and the pass's stores)
     __syncthreads();
     read_p3(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0, std::integral_constant<int, 0>{});
     FRX_STAMP(1);
     // (the last step still waits, syncs and reads "the fragments of step nk" -- zeros from the empty descriptors: one
     // barrier too many per tile buys a loop without a tail)
-    for (int cc = 0; cc < ncc; cc += 2) {
-      chunk9(std::integral_constant<int, 0>{}, cc);
-      chunk9(std::integral_constant<int, 1>{}, cc + 1);
+    if constexpr (NST != 0) {                           // (chunk 0 has waits of its own only where stores are counted)
+      chunk9(std::integral_constant<int, 0>{}, std::true_type{}, 0);
+      chunk9(std::integral_constant<int, 1>{}, std::false_type{}, 1);
+    }
+    for (int cc = NST != 0 ? 2 : 0; cc < ncc; cc += 2) {
+      chunk9(std::integral_constant<int, 0>{}, std::false_type{}, cc);
+      chunk9(std::integral_constant<int, 1>{}, std::false_type{}, cc + 1);
     }
     wait_vmcnt<0>();
   } else if constexpr (DMA) {

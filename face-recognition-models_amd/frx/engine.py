@@ -55,6 +55,7 @@ class ConvSpec:
     tot_b_buf: torch.Tensor = None
     tot_f: object = None     # ops.bn_tot(...) views for the consumers
     tot_b: object = None
+    patch_dgrad: bool = False    # 3x3 / stride 1 on the patch-mode kernel: its input gradient evaluates the BN backward itself
 
     @property
     def Ho(self):
@@ -155,6 +156,13 @@ class ResNet50Engine:
                 c.desc = ops.conv_desc(dtype, N, H, H, 3, 64, 7, 7, 2, 3, stem=True)
             else:
                 c.desc = ops.conv_desc(dtype, N, c.Hi, c.Hi, c.Ci, c.Co, c.k, c.k, c.stride, c.k // 2)
+                # (the per-tile partial rows of the deterministic form are laid out by frx_conv_tile's row tile.  Measured per
+                # layer inside a training step, fused dgrad vs bn_bwd_apply + prologue-free dgrad: 128- and 256-channel layers
+                # at batch 256 35.0 vs 32.4 + 9 us, 38.2 vs 35.5 + 8; the 64-column tile (two blocks per CU next to three
+                # patch buffers) 71.7 vs 43.2 + 20 and layer4's 64-pixel tile 53.8 vs 39.6 + 7 keep the separate pass)
+                pm = ops.conv_patch_mode(c.desc, True) if (c.k == 3 and c.stride == 1) else 0
+                c.patch_dgrad = (pm == 128 and c.Ci % 128 == 0 and pm == ops._igemm_tile(c.desc, True)[0]
+                                 and os.environ.get("FRX_PATCH_DGRAD", "1") != "0")
                 if c.k == 1 and c.stride == 2:
                     c.desc_c = ops.conv_desc(dtype, N, c.Ho, c.Ho, c.Ci, c.Co, 1, 1, 1, 0)
             if share is not None:
@@ -576,15 +584,22 @@ class ResNet50Engine:
             dz2 = self._like(S[4], c2.y)
             self._bwd_1x1(b, c3, dz3, C3, c2.y, dz2, x_bn=c2, **self._epi(c2))
             self._finalize_bwd(c2, ops.conv_dgrad_stat_rows(c3.desc), C2)
-            # conv2 (3x3): materialise dy2 once (9 taps would re-evaluate a prologue 9 times)
+            # conv2 (3x3).  Stride 1 (patch-mode kernel: every dy2 element is transformed once per staged patch): the dgrad
+            # evaluates dy2 = affine(dz2, y2) itself and stores it for the weight gradient on the way.  Stride 2 (nine taps
+            # would re-evaluate a prologue nine times): dy2 is materialised by a pass of its own first.
             rows2 = c2.y.numel() // c2.Co
-            if self.fused_bn:
-                ops.bn_bwd_apply_tot(dt, rows2, c2.Co, dz2, c2.y, c2.tot_b, b.dy2)
+            dz1 = self._like(S[3] if c2.patch_dgrad else S[4], c1.y)      # (the fused form reads dz2 = S[4] while it writes)
+            if c2.patch_dgrad:
+                pro = dict(pro_tot=c2.tot_b) if self.fused_bn else dict(pro_coef=C2)
+                ops.conv_dgrad_bn(c2.desc, dz2, c2.wt, dz1, pro_y=c2.y, pro_dy_out=b.dy2, **pro, **self._epi(c1))
+                self._wgrad(c2, c1.y, b.dy2, x_bn=c1)
             else:
-                ops.bn_bwd_apply(dt, rows2, c2.Co, dz2, c2.y, self._bn(self.bn_mean, c2), self._bn(self.bn_invstd, c2), C2, b.dy2)
-            self._wgrad(c2, c1.y, b.dy2, x_bn=c1)
-            dz1 = self._like(S[4], c1.y)
-            ops.conv_dgrad_bn(c2.desc, b.dy2, c2.wt, dz1, **self._epi(c1))
+                if self.fused_bn:
+                    ops.bn_bwd_apply_tot(dt, rows2, c2.Co, dz2, c2.y, c2.tot_b, b.dy2)
+                else:
+                    ops.bn_bwd_apply(dt, rows2, c2.Co, dz2, c2.y, self._bn(self.bn_mean, c2), self._bn(self.bn_invstd, c2), C2, b.dy2)
+                self._wgrad(c2, c1.y, b.dy2, x_bn=c1)
+                ops.conv_dgrad_bn(c2.desc, b.dy2, c2.wt, dz1, **self._epi(c1))
             self._finalize_bwd(c1, ops.conv_dgrad_stat_rows(c2.desc), C1)
             addend, add_stride = dz3, 0
             if ds is not None:

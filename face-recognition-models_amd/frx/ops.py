@@ -40,11 +40,12 @@ def _igemm_tile(d, dgrad=False):
 
 
 def conv_patch_mode(d, dgrad=False):
-    """frx_conv_patch_mode: does this layer's geometry take the patch-mode 3x3 kernel (given a prologue and no addend)"""
+    """frx_conv_patch_mode: the row tile (128 / 64) of the patch-mode 3x3 kernel if this layer's geometry takes it (given a
+    prologue and no addend), else 0"""
     r = _lib.lib().frx_conv_patch_mode(C.byref(d), int(dgrad))
     if r < 0:
         raise FrxError("conv descriptor rejected: " + _lib.lib().frx_last_error().decode())
-    return bool(r)
+    return r
 
 
 def _dt_name(dt):

@@ -200,10 +200,10 @@ int frx_conv_stat_rows(const frx_conv_desc* d);
 /* diagnostic (host logic only): the block tile (pixels x channels) frx_conv_fwd (dgrad = 0) or frx_conv_dgrad* (dgrad = 1)
  * launches for this layer -- what the profiling labels and the stat-row counts are derived from */
 int frx_conv_tile(const frx_conv_desc* d, int dgrad, int* bm, int* bn);
-/* diagnostic (host logic only): 1 if this layer's geometry (bf16, 3x3, stride 1, pad 1, images up to 30 pixels wide, a
+/* diagnostic (host logic only): the kernel's row tile (128 or 64 pixels) if this layer's geometry (bf16, 3x3, stride 1, pad 1, images up to 30 pixels wide, a
  * multiple of 64 gathered channels) puts frx_conv_fwd* (dgrad = 0) / frx_conv_dgrad_bn* (dgrad = 1) on the PATCH-MODE kernel
- * (csrc/conv_kernels.h "P3": a 128-pixel row tile whatever frx_conv_tile says) whenever the call carries a prologue and
- * no addend -- and, if it asks for per-tile partial statistics, frx_conv_tile's row tile is 128 as well.  0 otherwise; -1
+ * (csrc/conv_kernels.h "P3") whenever the call carries a prologue and
+ * no addend -- and, if it asks for per-tile partial statistics, frx_conv_tile's row tile is the same.  0 otherwise; -1
  * for a rejected descriptor.  FRX_CONV3X3=0 in the environment switches the kernel off. */
 int frx_conv_patch_mode(const frx_conv_desc* d, int dgrad);
 int frx_stem_padded_dims(int Hi, int Wi, int* Hp, int* Wp);

@@ -35,8 +35,13 @@ for N, H, W, Ci, Co in CASES:
         ops.conv_fwd(d, x, w, ye, in_scale=sc, in_shift=sh, in_relu=True)
         dx = torch.full((N, H, W, Ci), 7.0, device=DEV, dtype=torch.bfloat16)
         part2 = torch.zeros(ops.conv_dgrad_stat_rows(d) * 2 * Ci + 16, device=DEV)
-        ops.conv_dgrad_bn(d, dy, wt, dx, pro_y=yy, pro_coef=coef, epi_y=ey, epi_scale=esc, epi_shift=esh, epi_mean=emu, epi_invstd=eis, epi_partial=part2)
+        dyo = torch.full((N, H, W, Co), 7.0, device=DEV, dtype=torch.bfloat16)
+        ops.conv_dgrad_bn(d, dy, wt, dx, pro_y=yy, pro_coef=coef, epi_y=ey, epi_scale=esc, epi_shift=esh, epi_mean=emu, epi_invstd=eis, epi_partial=part2,
+                          pro_dy_out=dyo if v == "1" else None)
         torch.cuda.synchronize()
+        dyref = (coef[0] * dy.float() + coef[1] * yy.float() + coef[2]).bfloat16()
+        if v == "1" and not torch.equal(dyo, dyref):
+            print(f"  !! FRX_CONV3X3={v}: dy side output differs from alpha*dz + beta*y + gam: {(dyo.float() - dyref.float()).abs().max().item():.3e}"); bad += 1
         rows = ops.conv_stat_rows(d)
         st = part[: rows * 2 * Co].view(rows, 2, Co).sum(0)
         rows2 = ops.conv_dgrad_stat_rows(d)

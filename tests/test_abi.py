@@ -118,12 +118,12 @@ def test_conv_tile_choice_is_host_logic_and_consistent_with_the_stat_rows():
     assert L.frx_conv_dgrad_stat_rows(C.byref(d)) == 4 * -(-per_class // bm)
     # the patch-mode 3x3 kernel: geometry rule (bf16, 3x3 / stride 1 / pad 1, W <= 30, 64 | gathered channels), env switch
     import os
-    for shape, want in [((256, 28, 64, 64, 3, 1), 1), ((256, 14, 128, 128, 3, 1), 1), ((256, 7, 256, 256, 3, 1), 1), ((256, 4, 512, 512, 3, 1), 1),
+    for shape, want in [((256, 28, 64, 64, 3, 1), 128), ((256, 14, 128, 128, 3, 1), 128), ((256, 7, 256, 256, 3, 1), 128), ((256, 4, 512, 512, 3, 1), 64),
                         ((256, 28, 128, 128, 3, 2), 0), ((256, 28, 64, 256, 1, 1), 0), ((2, 56, 64, 64, 3, 1), 0), ((2, 14, 96, 64, 3, 1), 0)]:
         d = desc(*shape)
         assert L.frx_conv_patch_mode(C.byref(d), 0) == want, shape
     d = desc(2, 14, 96, 64, 3, 1)
-    assert L.frx_conv_patch_mode(C.byref(d), 1) == 1, "the input gradient gathers the 64 OUTPUT channels"
+    assert L.frx_conv_patch_mode(C.byref(d), 1) == 128, "the input gradient gathers the 64 OUTPUT channels"
     d32 = _lib.ConvDesc(0, 4, 14, 14, 128, 128, 3, 3, 1, 1, 14, 14, 0)
     assert L.frx_conv_patch_mode(C.byref(d32), 0) == 0, "fp32 keeps the chunk-per-tap kernel"
     old = os.environ.get("FRX_CONV3X3")
