@@ -80,7 +80,10 @@ static int launch_igemm(hipStream_t st, ConvArgs a, int dtype) {
     int bm3, bn3;
     p3_tile(a.M, a.Ncol, &bm3, &bn3);
     p3 = p3 && (!a.stat_partial || c.bm == bm3);
-    p3 = p3 && ((a.mode == MODE_FWD && has_pro && (epi == EPI_STATS || epi == EPI_PLAIN)) || (a.mode == MODE_DGRAD && a.X2 && epi == EPI_BNBWD));
+    // (prologue-free input gradient -- dy materialised by a pass of its own -- on the 64-column tile only: layer1, where
+    // the chunk-per-tap LDS-DMA kernel takes 43 us and the fused BN-backward prologue, two blocks per CU, 72)
+    p3 = p3 && ((a.mode == MODE_FWD && has_pro && (epi == EPI_STATS || epi == EPI_PLAIN)) ||
+                (a.mode == MODE_DGRAD && epi == EPI_BNBWD && (a.X2 || (!has_pro && bn3 == 64 && bm3 == 128))));
     if (p3) {
       a.tilesM = cdiv(a.M, bm3);
       a.tilesN = a.Ncol / bn3;

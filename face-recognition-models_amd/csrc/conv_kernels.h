@@ -692,21 +692,9 @@ __global__ __launch_bounds__(64 * WM * WN, (MODE == MODE_FWD3 || MODE == MODE_DG
     }
     constexpr int NST = PRO == 2 ? NPP : 0;             // stores per thread and patch: issued UNCONDITIONALLY (they count in vmcnt)
     const __amdgpu_buffer_rsrc_t rsrcDy0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.X), 0, 0u, 0x00020000);
-    // fragment row i of this lane at tap t: byte offset inside a patch buffer (the row of zeros when the tap leaves the image)
+    // fragment row i of this lane at tap t: byte offset inside a patch buffer (the row of zeros when the tap leaves the
+    // image); filled in after the tile's first loads have been issued
     unsigned aaddr[9][FM];
-#pragma unroll
-    for (int i = 0; i < FM; ++i) {
-      const int lr = wm * WTM + 16 * i + fr, pm = m0 + lr;
-      const bool ok = pm < a.M;
-      const int pp = ok ? pm : 0, n = pp / HWd, rem = pp - n * HWd, h = rem / Wd, w = rem - h * Wd;
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int dr = MODE == MODE_FWD3 ? t / 3 - 1 : 1 - t / 3, dc = MODE == MODE_FWD3 ? t % 3 - 1 : 1 - t % 3;
-        const bool valid = ok && (unsigned)(h + dr) < (unsigned)a.Hx && (unsigned)(w + dc) < (unsigned)Wd;
-        const int prow = lr + Wd + 1 + dr * Wd + dc;
-        aaddr[t][i] = valid ? (unsigned)(prow * 64 + ((fq ^ pswz(prow)) << 4)) : (unsigned)((PROWS - 1) * 64 + (fq << 4));
-      }
-    }
     const u32x4_t rawX2 = raw_rsrc(PRO == 2 ? a.X2 : a.X, a.xbytes), rawX0 = raw_rsrc(a.X, 0), rawW0 = raw_rsrc(a.W, 0);   // (..0: empty descriptors -- every lane out of range, the DMA writes zeros)
     int b_tap = 0, b_cc = 0;                            // (tap, channel chunk) of the next weight chunk to issue
     auto dma_b = [&](int stage) {                       // past the last chunk: zeros into a stage nobody reads (keeps the vmcnt arithmetic uniform)
@@ -809,6 +797,20 @@ __global__ __launch_bounds__(64 * WM * WN, (MODE == MODE_FWD3 || MODE == MODE_DG
     dma_patch(0, 0);
 #pragma unroll
     for (int j = 0; j < NS - 1; ++j) dma_b(j);
+    __builtin_amdgcn_sched_barrier(0);                  // (the tile's first loads are on their way before the arithmetic below)
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      const int lr = wm * WTM + 16 * i + fr, pm = m0 + lr;
+      const bool ok = pm < a.M;
+      const int pp = ok ? pm : 0, n = pp / HWd, rem = pp - n * HWd, h = rem / Wd, w = rem - h * Wd;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) {
+        const int dr = MODE == MODE_FWD3 ? t / 3 - 1 : 1 - t / 3, dc = MODE == MODE_FWD3 ? t % 3 - 1 : 1 - t % 3;
+        const bool valid = ok && (unsigned)(h + dr) < (unsigned)a.Hx && (unsigned)(w + dc) < (unsigned)Wd;
+        const int prow = lr + Wd + 1 + dr * Wd + dc;
+        aaddr[t][i] = valid ? (unsigned)(prow * 64 + ((fq ^ pswz(prow)) << 4)) : (unsigned)((PROWS - 1) * 64 + (fq << 4));
+      }
+    }
     fill_pro_tables();
     wait_vmcnt<(NS - 1) * BLD>();                       // patch 0 is older than every weight chunk
     fix_patch(0, 0);

@@ -19,7 +19,8 @@ int launch_igemm_p3(hipStream_t st, const ConvArgs& a, int epi, int bm, int bn) 
     else if (epi == EPI_PLAIN) FRX_P3_T(MODE_FWD3, 1, EPI_PLAIN, 5, 5);
     else { set_error("igemm p3 fwd: unsupported epilogue %d", epi); return FRX_ERR_ARG; }
   } else {
-    if (epi == EPI_BNBWD) FRX_P3_T(MODE_DGRAD3, 2, EPI_BNBWD, 4, 4);
+    if (epi == EPI_BNBWD && a.X2) FRX_P3_T(MODE_DGRAD3, 2, EPI_BNBWD, 4, 4);
+    else if (epi == EPI_BNBWD && bn == 64) FRX_P3(128, 64, 2, 2, MODE_DGRAD3, 0, EPI_BNBWD, 6);      // materialised dy (layer1: see conv.hip)
     else { set_error("igemm p3 dgrad: unsupported epilogue %d", epi); return FRX_ERR_ARG; }
   }
   FRX_LAUNCH_CHECK();

@@ -69,6 +69,11 @@ class DataParallelStep:
                             and getattr(engine, "shard", None) is None)
         if self.head_bucket and hasattr(engine, "set_head_bucket"):
             engine.set_head_bucket(True)
+        # one graph for the whole step: the upper weight-gradient list may still run (side stream, FRX_WGRAD_STREAM=1) while
+        # the lower backward proceeds; with buckets its gradients must be final where the "upper" segment ends
+        net = getattr(engine, "net", None)
+        if net is not None and hasattr(net, "join_after_upper"):
+            net.join_after_upper = self.multi
         self.images = self.labels = None
         if static_inputs is not None:
             self.images, self.labels = static_inputs

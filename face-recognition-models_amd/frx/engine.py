@@ -206,6 +206,11 @@ class ResNet50Engine:
         self.g_pool = torch.zeros_like(self.pool_out)        # gradient w.r.t. the max-pool output
         self.dy_stem = torch.zeros_like(self.stem.y)
         self.grouped_wgrad = os.environ.get("FRX_WGRAD_GROUPED", "1") != "0"
+        # FRX_WGRAD_STREAM=1: the grouped weight-gradient lists run on a side stream next to the input gradients of the layers
+        # below them (a fork / join inside the captured step)
+        self.wgrad_stream = (torch.cuda.Stream(device=dev) if (dev.type == "cuda" and self.grouped_wgrad
+                                                              and os.environ.get("FRX_WGRAD_STREAM", "0") == "1") else None)
+        self.join_after_upper = True
         # bf16 speed mode: BatchNorm statistics travel as replicated totals the producers add into with float atomics
         # and every consumer derives its constants from (no finalize launch per layer: -104 launches per step).  The fp32
         # parity mode and FRX_BN_DETERMINISTIC=1 keep partial rows + finalize launches (bit-reproducible sums).
@@ -553,14 +558,25 @@ class ResNet50Engine:
         self._backward_blocks(len(self.blocks) - 1, self.SPLIT_BLOCK)
         self._close_bn_bwd(0)
         self._run_wgrad_group(0)
+        if self.join_after_upper:          # (the upper gradient ranges are final when this returns: what a bucket's all-reduce needs)
+            self.join_wgrad()
 
     def backward_lower(self):
-        self._backward_blocks(self.SPLIT_BLOCK - 1, 0)
-        self._backward_stem()
-        self._close_bn_bwd(1)
-        self._run_wgrad_group(1)
+        if self.wgrad_stream is not None:
+            # layer2's list starts as soon as layer2's input gradients are done and runs next to layer1's
+            self._backward_blocks(self.SPLIT_BLOCK - 1, LAYERS[0])
+            self._close_bn_bwd(1)
+            self._run_wgrad_group(1)
+            self._backward_blocks(LAYERS[0] - 1, 0)
+            self._backward_stem()
+        else:
+            self._backward_blocks(self.SPLIT_BLOCK - 1, 0)
+            self._backward_stem()
+            self._close_bn_bwd(1)
+            self._run_wgrad_group(1)
         self._close_bn_bwd(2)
         self._run_wgrad_group(2)
+        self.join_wgrad()
 
     def _close_bn_bwd(self, which):
         """replicated totals of one group of BatchNorm layers -> dgamma / dbeta (+=) and the coefficient arrays the grouped
@@ -725,7 +741,20 @@ class ResNet50Engine:
             return
         if self._wg_groups is None:
             self._plan_wgrad_groups()
-        ops.wgrad_group_run(self._wg_groups[which])
+        if self.wgrad_stream is None:
+            ops.wgrad_group_run(self._wg_groups[which])
+            return
+        # fork: the list runs on the side stream, next to the input gradients of the layers below (it reads per-block
+        # buffers and writes its own gradient ranges only); join_wgrad() brings the streams back together
+        self.wgrad_stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.wgrad_stream):
+            ops.wgrad_group_run(self._wg_groups[which])
+        self._wgrad_forked = True
+
+    def join_wgrad(self):
+        if getattr(self, "_wgrad_forked", False):
+            torch.cuda.current_stream(self.device).wait_stream(self.wgrad_stream)
+            self._wgrad_forked = False
 
     # ------------------------------------------------------------------ optimiser
     def zero_grad(self):

@@ -224,9 +224,14 @@ def test_patch_3x3_input_gradient_vs_aten(case):
     out = torch.full((N, H, W, Ci), float("nan"), dtype=T, device=DEV)
     wt = w.permute(3, 1, 2, 0).contiguous().to(DEV)
     dv = lambda t: t.to(DEV)
+    dy_side = torch.full((N, H, W, Co), float("nan"), dtype=T, device=DEV)     # the transformed operand, kept for the weight gradient
     ops.conv_dgrad_bn(d, dv(dz), wt, out, pro_y=dv(yraw), pro_coef=dv(coef), epi_y=dv(ey), epi_scale=dv(esc), epi_shift=dv(esh),
-                      epi_mean=dv(emu), epi_invstd=dv(eis), epi_totals=tot, epi_replicas=R)
+                      epi_mean=dv(emu), epi_invstd=dv(eis), epi_totals=tot, epi_replicas=R, pro_dy_out=dy_side)
     _close(out, ref, 1, "patch dgrad: dz")
+    assert torch.isfinite(dy_side.float()).all(), "side output has unwritten elements"
+    # (the kernel evaluates fma(alpha, dz, fma(beta, y, gam)): one bf16 ulp where the two roundings differ)
+    assert (dy_side.float().cpu() - dy).abs().max().item() <= 2.0 ** -7 * dy.abs().max().item()
+    assert (dy_side.float().cpu() != dy).float().mean().item() < 2e-3
     # a masked element whose pre-activation is within rounding of 0 may flip: compare the statistics on the kernel's own dz
     oq = out.float().cpu()
     xhat = (ey.float() - emu) * eis
