@@ -90,6 +90,9 @@ static int launch_igemm(hipStream_t st, ConvArgs a, int dtype) {
       a.nvb = (int)round_up(a.tilesM, 8) * a.tilesN;
       return launch_igemm_p3(st, a, epi, bm3, bn3);
     }
+    FRX_CHECK_ARG(!(a.dy_out && a.mode == MODE_FWD),
+                  "conv_fwd_keep: x_norm_out needs the patch-mode launch (partial-statistics rows only where frx_conv_tile's row tile is "
+                  "frx_conv_patch_mode's)");
     FRX_CHECK_ARG(!(a.dy_out && (a.R != 1 || a.S != 1)),
                   "conv_dgrad_bn: pro_dy_out on a 3x3 needs the patch-mode launch (BN-backward prologue, masked-statistics epilogue, no "
                   "addend; partial-statistics rows only where frx_conv_tile's row tile is frx_conv_patch_mode's)");
@@ -175,8 +178,13 @@ extern "C" int frx_stem_padded_dims(int Hi, int Wi, int* Hp, int* Wp) {
 static int conv_fwd_impl(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x,
                          const void* w, const float* in_scale, const float* in_shift, int in_relu,
                          const float* bias, void* y, int out_f32, float* stat_partial, const frx_bn_tot* in_bn,
-                         float* stat_totals, int stat_replicas) {
+                         float* stat_totals, int stat_replicas, void* x_norm_out = nullptr) {
   if (int rc = check_conv(d)) return rc;
+  if (x_norm_out) {
+    FRX_CHECK_ARG(in_scale || in_bn, "conv_fwd_keep: x_norm_out is the prologue's output: needs in_scale / in_shift or in_bn");
+    FRX_CHECK_ARG(!d->stem && p3_geometry(d->dtype, d->R, d->S, d->stride, d->pad, d->Wi, d->Ci),
+                  "conv_fwd_keep: x_norm_out needs a layer on the patch-mode kernel (frx_conv_patch_mode)");
+  }
   if (in_bn) {
     FRX_CHECK_ARG(!d->stem, "conv_fwd_tot: the stem takes the raw image (no prologue)");
     FRX_CHECK_ARG(in_bn->totals && in_bn->gamma && in_bn->beta && frx_pow2(in_bn->replicas) && in_bn->count > 0.f,
@@ -196,6 +204,7 @@ static int conv_fwd_impl(int device, frx_stream_t stream, const frx_conv_desc* d
   a.in_scale = in_scale; a.in_shift = in_shift; a.in_relu = in_relu;
   a.bias = bias; a.stat_partial = stat_partial; a.out_f32 = out_f32;
   a.in_tot = bn_tot_arg(in_bn); a.stat_tot = stat_totals; a.stat_R = stat_replicas;
+  a.dy_out = x_norm_out;
   a.N = d->N; a.Ho = d->Ho; a.Wo = d->Wo; a.Ncol = d->Co; a.R = d->R; a.S = d->S;
   a.stride = d->stride; a.pad = d->pad;
   a.M = d->N * d->Ho * d->Wo;
@@ -213,6 +222,15 @@ extern "C" int frx_conv_fwd(int device, frx_stream_t stream, const frx_conv_desc
                             const void* w, const float* in_scale, const float* in_shift, int in_relu,
                             const float* bias, void* y, int out_f32, float* stat_partial) {
   return conv_fwd_impl(device, stream, d, x, w, in_scale, in_shift, in_relu, bias, y, out_f32, stat_partial, nullptr, nullptr, 0);
+}
+
+extern "C" int frx_conv_fwd_keep(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x, const void* w,
+                                 const float* in_scale, const float* in_shift, const frx_bn_tot* in_bn, int in_relu, void* y,
+                                 float* stat_partial, float* stat_totals, int stat_replicas, void* x_norm_out) {
+  FRX_CHECK_ARG(!(in_scale && in_bn), "conv_fwd_keep: prologue constants as arrays OR as totals");
+  FRX_CHECK_ARG(!(stat_partial && stat_totals), "conv_fwd_keep: statistics as partial rows OR as totals");
+  return conv_fwd_impl(device, stream, d, x, w, in_scale, in_shift, in_relu, nullptr, y, 0, stat_partial, in_bn, stat_totals, stat_replicas,
+                       x_norm_out);
 }
 
 extern "C" int frx_conv_fwd_tot(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x, const void* w,

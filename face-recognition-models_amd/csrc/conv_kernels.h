@@ -66,7 +66,7 @@ struct ConvArgs {
   // PRO == 2 (dgrad): the gathered operand is the BN backward  alpha*dz + beta*y + gam  of two tensors
   const void* X2;         //   y (raw conv output), same indexing as X (= dz); in_scale = alpha, in_shift = beta
   const float* pro_gam;   //   gam [Kc]
-  void* dy_out;           //   optional (1x1): the transformed operand is also stored here, same indexing as X
+  void* dy_out;           //   optional (1x1 with PRO == 2; patch mode with any prologue): the transformed operand is also stored here, same indexing as X
   // epi_bnbwd (dgrad): the output is the gradient w.r.t. a post-BN(-ReLU) activation; mask it, write dz and
   // reduce  sum(dz), sum(dz*xhat)  per channel into stat_partial (what frx_bn_bwd_reduce does in a pass of its own)
   int epi_bnbwd;
@@ -404,8 +404,10 @@ __global__ __launch_bounds__(64 * WM * WN, (MODE == MODE_FWD3 || MODE == MODE_DG
   // PRO == 2 side output: the first column of tiles stores the transformed operand (dy).  The store is
   // unconditional (a branch in the K loop would cost the counted waits); every other block gets an EMPTY
   // descriptor, which drops the stores.
+  // (patch mode: also the forward's transformed operand, relu(bn(x)), for the 3x3 weight gradient)
+  constexpr bool SIDE = PRO == 2 || (PRO == 1 && (MODE == MODE_FWD3 || MODE == MODE_DGRAD3));
   const __amdgpu_buffer_rsrc_t rsrcDy = __builtin_amdgcn_make_buffer_rsrc(
-      (PRO == 2 && a.dy_out) ? a.dy_out : const_cast<void*>(a.X), 0, (PRO == 2 && a.dy_out && nt == 0) ? a.xbytes : 0u, 0x00020000);
+      (SIDE && a.dy_out) ? a.dy_out : const_cast<void*>(a.X), 0, (SIDE && a.dy_out && nt == 0) ? a.xbytes : 0u, 0x00020000);
   constexpr unsigned OOB = 0x80000000u;
   unsigned bvoff[BLD];
 #pragma unroll
@@ -686,11 +688,11 @@ __global__ __launch_bounds__(64 * WM * WN, (MODE == MODE_FWD3 || MODE == MODE_DG
       pvoff[u] = ok ? (unsigned)((pix * a.Kc + lc * VEC) * (int)sizeof(T)) : OOB;
       ptab[u] = lc * VEC * NTAB;
       pfix[u] = row < PR;
-      // PRO == 2 side output (dy = the transformed operand, for the weight gradient): every pixel is the OWN row of exactly
+      // side output (the transformed operand, for the weight gradient: dy, or the forward's relu(bn(x))): every pixel is the OWN row of exactly
       // one row tile (patch rows W + 1 .. W + BM); the first column of tiles stores them (rsrcDy is empty elsewhere)
       pstoff[u] = (ok && row > Wd && row <= Wd + BM) ? pvoff[u] : OOB;
     }
-    constexpr int NST = PRO == 2 ? NPP : 0;             // stores per thread and patch: issued UNCONDITIONALLY (they count in vmcnt)
+    constexpr int NST = PRO != 0 ? NPP : 0;             // stores per thread and patch: issued UNCONDITIONALLY (they count in vmcnt)
     const __amdgpu_buffer_rsrc_t rsrcDy0 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.X), 0, 0u, 0x00020000);
     // fragment row i of this lane at tap t: byte offset inside a patch buffer (the row of zeros when the tap leaves the
     // image); filled in after the tile's first loads have been issued
@@ -730,7 +732,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MODE == MODE_FWD3 || MODE == MODE_DG
             else v = affine2_vec<T>(v, *reinterpret_cast<const uint4*>(smem + 2 * PBUF + (u * NT + tid) * 16), tb, tb + VEC, tb + 2 * VEC);
             *reinterpret_cast<uint4*>(pp) = v;
           }
-          if constexpr (PRO == 2) {      // (soffset stays the literal 0: see the note on stores in the epilogue)
+          if constexpr (PRO != 0) {      // (soffset stays the literal 0: see the note on stores in the epilogue)
             u32x4_t sv; sv[0] = v.x; sv[1] = v.y; sv[2] = v.z; sv[3] = v.w;
             __builtin_amdgcn_raw_buffer_store_b128(sv, rdy, pstoff[u] + (unsigned)(cc * CE * (int)sizeof(T)), 0, 0);
           }

@@ -334,6 +334,18 @@ def conv_fwd_tot(d, x, w, y, in_bn=None, in_relu=True, stat_totals=None, stat_re
     return y
 
 
+def conv_fwd_keep(d, x, w, y, x_norm_out, in_scale=None, in_shift=None, in_bn=None, in_relu=True, stat_partial=None,
+                  stat_totals=None, stat_replicas=0):
+    """frx_conv_fwd_keep: the forward of a patch-mode 3x3 layer that also stores its prologue's output relu(bn(x))"""
+    bm, bn = _igemm_tile(d) if PROFILER is not None else (0, 0)
+    _timed(f"k_igemm<{_dt_name(d.dtype)},{bm},{bn}>", conv_flops(d), x, lambda: check(
+        _lib.lib().frx_conv_fwd_keep(_dev(x), _stream(x), C.byref(d), _p(x), _p(w), _p(in_scale), _p(in_shift),
+                                     C.byref(in_bn) if in_bn is not None else None, int(in_relu), _p(y), _p(stat_partial),
+                                     _p(stat_totals), int(stat_replicas), _p(x_norm_out)), "frx_conv_fwd_keep"),
+        nbytes=conv_bytes(d))
+    return y
+
+
 def conv_dgrad(d, dy, w_crsk, dx, addend=None):
     bm, bn = _igemm_tile(d, True) if PROFILER is not None else (0, 0)
     _timed(f"k_igemm<{_dt_name(d.dtype)},{bm},{bn}>", conv_flops(d), dy, lambda: check(

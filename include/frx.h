@@ -228,6 +228,14 @@ typedef struct frx_bn_tot {
  * stat_totals [stat_replicas][2][Co] (NULL: none) */
 int frx_conv_fwd_tot(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x, const void* w_krsc,
                      const frx_bn_tot* in_bn, int in_relu, void* y, float* stat_totals, int stat_replicas);
+/* frx_conv_fwd / frx_conv_fwd_tot (prologue constants as arrays OR as totals, statistics as partial rows OR as totals, or
+ * none) that also KEEPS the prologue's output  x_norm_out = relu(scale * x + shift)  (same shape and dtype as x) -- what the
+ * 3x3 weight gradient otherwise re-evaluates once per staged tap (torch autograd saves this tensor: the input of nn.Conv2d
+ * conv2 in torchvision's Bottleneck).  Patch-mode layers only (frx_conv_patch_mode(d, 0) != 0, and with stat_partial its row
+ * tile = frx_conv_tile's): there every element is transformed exactly once, by the block that owns its pixel row. */
+int frx_conv_fwd_keep(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x, const void* w_krsc,
+                      const float* in_scale, const float* in_shift, const frx_bn_tot* in_bn, int in_relu, void* y,
+                      float* stat_partial, float* stat_totals, int stat_replicas, void* x_norm_out);
 /* y = conv(f(x), w) [+ bias]; out_f32 stores y as fp32 (the fc layer feeding the head) */
 int frx_conv_fwd(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x, const void* w_krsc,
                  const float* in_scale, const float* in_shift, int in_relu, const float* bias, void* y,

@@ -163,6 +163,16 @@ def test_patch_3x3_forward_vs_aten(case):
     y = torch.full((N, H, W, Co), float("nan"), dtype=x.dtype, device=DEV)
     ops.conv_fwd(d, xd, wd, y, in_scale=scd, in_shift=shd, in_relu=True)
     _close(y, ref, 1, "patch fwd, plain epilogue")
+    # the same launch keeping its prologue's output (what the 3x3 weight gradient stages): every element, exactly
+    xn = torch.full((N, H, W, Ci), float("nan"), dtype=x.dtype, device=DEV)
+    yk = torch.full_like(y, float("nan"))
+    ops.conv_fwd_keep(d, xd, wd, yk, xn, in_scale=scd, in_shift=shd, in_relu=True)
+    assert torch.equal(yk, y)
+    want = torch.relu(torch.addcmul(sh, x.float(), sc)).to(x.dtype)          # fma(x, scale, shift), as the kernel evaluates it
+    got = xn.cpu()
+    assert torch.isfinite(got.float()).all(), "kept input has unwritten elements"
+    assert (got.float() - want.float()).abs().max().item() <= 2.0 ** -7 * want.float().abs().max().item()
+    assert (got != want).float().mean().item() < 2e-3
     # statistics into R replicated rows (the training step's form); the prologue constants given as arrays here
     R = 4
     tot = torch.zeros(R, 2, Co, device=DEV)
