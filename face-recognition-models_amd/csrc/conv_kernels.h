@@ -282,14 +282,14 @@ static inline unsigned igemm_pro_lds(int pro, int Kc) { return pro ? (pro == 2 ?
 
 // MODE (gather geometry) and PRO (BN+ReLU prologue) are compile-time so the steady-state K loop is
 // straight-line code: hipcc then keeps counted s_waitcnt vmcnt(N) for the register ring.
-template <typename T, int BM, int BN, int WM, int WN, int MODE, int PRO, int EPI, bool ADD, int KC = 64, int PD = 3, int NS = 0, bool PERSIST = false>   // PRO: 0 none, 1 BN+ReLU, 2 BN-backward affine; KC: bytes of the contraction axis per row and K-chunk; PD: ring depth; NS > 0: LDS-DMA staging into a ring of NS LDS stages (PRO == 0 only) instead of the register ring
+template <typename T, int BM, int BN, int WM, int WN, int MODE, int PRO, int EPI, bool ADD, int KC = 64, int PD = 3, int NS = 0, bool PERSIST = false, bool SPEC = false>   // PRO: 0 none, 1 BN+ReLU, 2 BN-backward affine; KC: bytes of the contraction axis per row and K-chunk; PD: ring depth; NS > 0: LDS-DMA staging into a ring of NS LDS stages (PRO == 0 only) instead of the register ring
 // waves per SIMD the register budget must allow: 3 where the kernel fits 168 registers without spilling (measured:
 // +10-20 % on the prologue-free variants), 2 for the BN-prologue variants (they spill 35-50 registers at 3)
 // (WM x WN = 4 waves; or 8 waves on a 128x128 tile for launches with too few tiles to give every SIMD two waves)
 #ifndef FRX_OCC4W            // tuning aid: blocks per CU the four-wave tiles are compiled for (0: the table below)
 #define FRX_OCC4W 0
 #endif
-__global__ __launch_bounds__(64 * WM * WN, (MODE == MODE_FWD3 || MODE == MODE_DGRAD3) ? (BN == 64 ? 3 : 2) : (NS > 4) ? (WM * WN) / 4 : (KC == 128 || PD > 3) ? 2 : (WM * WN == 8 ? 4 : (FRX_OCC4W ? FRX_OCC4W : ((PRO == 0 && EPI != EPI_BNBWD_OUT && !ADD) ? 3 : 2)))) void k_igemm(ConvArgs ka) {
+__global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1), SPEC ? 1 : (MODE == MODE_FWD3 || MODE == MODE_DGRAD3) ? (BN == 64 ? 3 : 2) : (NS > 4) ? (WM * WN) / 4 : (KC == 128 || PD > 3) ? 2 : (WM * WN == 8 ? 4 : (FRX_OCC4W ? FRX_OCC4W : ((PRO == 0 && EPI != EPI_BNBWD_OUT && !ADD) ? 3 : 2)))) void k_igemm(ConvArgs ka) {
   // P3 (MODE_FWD3 / MODE_DGRAD3): 3x3, stride 1, pad 1.  The rows a tile gathers over its nine taps are the CONTIGUOUS pixel
   // range [m0 - W - 1, m0 + BM + W + 1) of the flattened (n, h, w) axis, so per 64-byte channel chunk that range is staged
   // ONCE as a patch (LDS-DMA, then the BN prologue in place on the staging thread's own 16-byte pieces) and the nine taps
@@ -301,6 +301,11 @@ __global__ __launch_bounds__(64 * WM * WN, (MODE == MODE_FWD3 || MODE == MODE_DG
   constexpr bool DMA = NS > 0 && !P3;
   static_assert(!DMA || (PRO == 0 && MODE != MODE_STEM && NS >= 3 && NS <= 8), "LDS-DMA staging: prologue-free launches, 3 to 8 stages");
   static_assert(!P3 || (KC == 64 && NS >= 4 && NS <= 8 && !PERSIST && sizeof(T) == 2), "patch mode: bf16, 64-byte chunks, 4 to 8 weight stages");
+  // SPEC (patch mode, launches with at most one block per CU): WM x WN MORE waves per block that do nothing but stage -- weight
+  // DMA, patch DMA, prologue pass, side-output stores -- while the first WM x WN only read fragments and issue MFMAs.  A lone
+  // wave per SIMD issues one instruction per 4 clocks and ran a step's parts back to back (MFMA 256-295 + weight DMA 140 +
+  // fragment reads 140 + patch 140 clocks, profiles/r03_p3_ablation_stamps.txt); two waves per SIMD with different jobs overlap.
+  static_assert(!SPEC || P3, "staging waves exist in patch mode only");
   constexpr int VEC = TT<T>::VEC, CE = KC / (int)sizeof(T);      // elements per 16-byte load; elements per K-chunk
   constexpr int CPR = KC / 16;                                   // 16-byte slots per row of the LDS image
   constexpr int NT = 64 * WM * WN, RPP = NT / CPR;     // threads; tile rows staged per pass (CPR x 16-byte loads per row)
@@ -357,7 +362,9 @@ __global__ __launch_bounds__(64 * WM * WN, (MODE == MODE_FWD3 || MODE == MODE_DG
   if constexpr (PERSIST) asm volatile("" : "+v"(tid_l));      // (per-thread constants are re-derived per tile, not kept live across the epilogue)
   const int tid = tid_l, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int chunk = tid & (CPR - 1), srow = tid / CPR;
+  const bool loader = SPEC && __builtin_amdgcn_readfirstlane(wave) >= WM * WN;      // (wave-uniform) a staging wave
+  const int stid = SPEC ? (tid & (NT - 1)) : tid;                                   // thread index among the staging threads
+  const int chunk = stid & (CPR - 1), srow = stid / CPR;
   // LDS-DMA writes lane-linear, so the XOR swizzle of the LDS image moves to the SOURCE side: the thread whose bytes land in
   // slot `chunk` of its row fetches the logical chunk that belongs there (the same involution the fragment reads apply)
   const int lchunk = (DMA || P3) ? (chunk ^ swz_row<KC>(srow)) : chunk;
@@ -516,7 +523,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MODE == MODE_FWD3 || MODE == MODE_DG
   // 64 / CPR tile rows starting at row w * 64 / CPR + RPP * i, lane-linear); nothing waits here
   const u32x4_t rawX = raw_rsrc(a.X, a.xbytes), rawW = raw_rsrc(a.W, a.wbytes);
   const unsigned lds0 = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)smem;
-  const unsigned wrow = (unsigned)__builtin_amdgcn_readfirstlane(wave) * 1024u;     // this wave's slice of every RPP-row pass
+  const unsigned wrow = (unsigned)__builtin_amdgcn_readfirstlane(SPEC ? (wave & (WM * WN - 1)) : wave) * 1024u;     // this wave's slice of every RPP-row pass
   auto dma_chunk = [&](int kc, int stage) {
     const int so = c0 * (int)sizeof(T);
     const unsigned sa = lds0 + (unsigned)stage * STAGE + wrow, sb = sa + BM * KC;
@@ -683,7 +690,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MODE == MODE_FWD3 || MODE == MODE_DG
     bool pfix[NPP];
 #pragma unroll
     for (int u = 0; u < NPP; ++u) {
-      const int q = u * NT + tid, row = q >> 2, lc = (q & 3) ^ pswz(row), pix = plo + row;
+      const int q = u * NT + stid, row = q >> 2, lc = (q & 3) ^ pswz(row), pix = plo + row;
       const bool ok = row < PR && pix >= 0 && pix < a.M;
       pvoff[u] = ok ? (unsigned)((pix * a.Kc + lc * VEC) * (int)sizeof(T)) : OOB;
       ptab[u] = lc * VEC * NTAB;
@@ -700,6 +707,10 @@ __global__ __launch_bounds__(64 * WM * WN, (MODE == MODE_FWD3 || MODE == MODE_DG
     const u32x4_t rawX2 = raw_rsrc(PRO == 2 ? a.X2 : a.X, a.xbytes), rawX0 = raw_rsrc(a.X, 0), rawW0 = raw_rsrc(a.W, 0);   // (..0: empty descriptors -- every lane out of range, the DMA writes zeros)
     int b_tap = 0, b_cc = 0;                            // (tap, channel chunk) of the next weight chunk to issue
     auto dma_b = [&](int stage) {                       // past the last chunk: zeros into a stage nobody reads (keeps the vmcnt arithmetic uniform)
+      if constexpr (SPEC) {      // (inside the staging waves' branch hipcc otherwise treats the walkers as divergent: VGPR operands in the asm)
+        b_cc = __builtin_amdgcn_readfirstlane(b_cc); b_tap = __builtin_amdgcn_readfirstlane(b_tap);
+        stage = __builtin_amdgcn_readfirstlane(stage);
+      }
       const u32x4_t rw = b_cc < ncc ? rawW : rawW0;
       const int sob = (b_tap * a.Kc + b_cc * CE) * (int)sizeof(T);
       const unsigned sb = lds0 + NPATCH * PBUF + (unsigned)stage * BST + wrow;
@@ -708,6 +719,7 @@ __global__ __launch_bounds__(64 * WM * WN, (MODE == MODE_FWD3 || MODE == MODE_DG
       if (++b_tap == 9) { b_tap = 0; ++b_cc; }
     };
     auto dma_patch = [&](int cc, int buf) {
+      if constexpr (SPEC) cc = __builtin_amdgcn_readfirstlane(cc);
       const bool live = cc < ncc;
       const u32x4_t rx = live ? rawX : rawX0, rx2 = live ? rawX2 : rawX0;
       const int so = cc * CE * (int)sizeof(T);
@@ -725,11 +737,11 @@ __global__ __launch_bounds__(64 * WM * WN, (MODE == MODE_FWD3 || MODE == MODE_DG
         for (int u = 0; u < NPP; ++u) {
           uint4 v = make_uint4(0, 0, 0, 0);
           if (pfix[u]) {
-            char* pp = smem + buf * PBUF + (u * NT + tid) * 16;
+            char* pp = smem + buf * PBUF + (u * NT + stid) * 16;
             v = *reinterpret_cast<uint4*>(pp);
             const float* tb = s_pro + cc * CE * NTAB + ptab[u];
             if constexpr (PRO == 1) v = bn_relu_vec<T>(v, tb, tb + VEC, a.in_relu);
-            else v = affine2_vec<T>(v, *reinterpret_cast<const uint4*>(smem + 2 * PBUF + (u * NT + tid) * 16), tb, tb + VEC, tb + 2 * VEC);
+            else v = affine2_vec<T>(v, *reinterpret_cast<const uint4*>(smem + 2 * PBUF + (u * NT + stid) * 16), tb, tb + VEC, tb + 2 * VEC);
             *reinterpret_cast<uint4*>(pp) = v;
           }
           if constexpr (PRO != 0) {      // (soffset stays the literal 0: see the note on stores in the epilogue)
@@ -756,7 +768,10 @@ __global__ __launch_bounds__(64 * WM * WN, (MODE == MODE_FWD3 || MODE == MODE_DG
     // k + NS - 1 into the stage chunk k - 1 just left | t = 0: DMA of patch cc + 1 into the other buffer (last read two
     // barriers ago) | fragments of step k + 1 | t = TF: prologue on patch cc + 1 (visible after the next barrier, first read
     // at t = 8) | MFMAs of step k.  Straight-line per pair of chunks: every count below is a compile-time constant.
-    auto step = [&](auto t_tag, auto buf_tag, auto first_tag, int cc) {
+    // ROLE: 0 every wave does everything; SPEC: 1 a staging wave's share of the step, 2 a computing wave's (the two loops are
+    // separate code -- a role branch inside the step would join two register assignments sixteen times per chunk pair)
+    auto step = [&](auto t_tag, auto buf_tag, auto first_tag, auto role_tag, int cc) {
+      constexpr int ROLE = decltype(role_tag)::value;
       constexpr int t = decltype(t_tag)::value, BUF = decltype(buf_tag)::value, P = (t + BUF) & 1;      // P = k & 1 (9 cc = cc mod 2)
       constexpr bool FIRST = decltype(first_tag)::value;                                               // chunk 0 of the tile
       const int nxt = stg + 1 == NS ? 0 : stg + 1, prv = stg == 0 ? NS - 1 : stg - 1;
@@ -768,6 +783,29 @@ __global__ __launch_bounds__(64 * WM * WN, (MODE == MODE_FWD3 || MODE == MODE_DG
 #ifndef FRX_P3_ABL          // timing ablations (wrong results): 1 no weight DMA, 2 no fragment reads, 4 no barrier, 8 no MFMA, 16 no patch DMA / prologue
 #define FRX_P3_ABL 0
 #endif
+      if constexpr (ROLE != 0) {
+        if constexpr (ROLE == 1) {
+          wait_vmcnt<(NS - 3) * BLD + ((t >= 1 && t <= NS - 2) ? NPL : 0) + (ST ? NST : 0)>();
+          __builtin_amdgcn_s_barrier();
+          dma_b(prv);
+          if constexpr (t == 0) dma_patch(cc + 1, 1 - BUF);
+          if constexpr (t == TF) fix_patch(cc + 1, 1 - BUF);
+        } else {
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+          read_p3(std::integral_constant<int, (t + 1) % 9>{}, std::integral_constant<int, (t == 8 ? 1 - BUF : BUF)>{}, nxt, std::integral_constant<int, 1 - P>{});
+          mfma_frags(std::integral_constant<int, P>{});
+#pragma unroll
+          for (int q = 0; q < FM * FN; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (q < FM + FN) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        stg = nxt;
+        return;
+      }
       wait_vmcnt<(NS - 3) * BLD + ((t >= 1 && t <= NS - 2) ? NPL : 0) + (ST ? NST : 0)>();
       if constexpr (!(FRX_P3_ABL & 4)) __builtin_amdgcn_s_barrier();
       __builtin_amdgcn_sched_barrier(0);                // (MFMAs touch registers only: without this hipcc pulls the NEXT step's up to right behind their fragment reads)
@@ -788,17 +826,29 @@ __global__ __launch_bounds__(64 * WM * WN, (MODE == MODE_FWD3 || MODE == MODE_DG
       __builtin_amdgcn_sched_barrier(0);                // (this step's MFMAs stay in front of the next barrier, i.e. behind reads issued a step earlier)
       stg = nxt;
     };
-    auto chunk9 = [&](auto buf_tag, auto first_tag, int cc) {
-      step(std::integral_constant<int, 0>{}, buf_tag, first_tag, cc); step(std::integral_constant<int, 1>{}, buf_tag, first_tag, cc);
-      step(std::integral_constant<int, 2>{}, buf_tag, first_tag, cc); step(std::integral_constant<int, 3>{}, buf_tag, first_tag, cc);
-      step(std::integral_constant<int, 4>{}, buf_tag, first_tag, cc); step(std::integral_constant<int, 5>{}, buf_tag, first_tag, cc);
-      step(std::integral_constant<int, 6>{}, buf_tag, first_tag, cc); step(std::integral_constant<int, 7>{}, buf_tag, first_tag, cc);
-      step(std::integral_constant<int, 8>{}, buf_tag, first_tag, cc);
+    auto chunk9 = [&](auto buf_tag, auto first_tag, auto role_tag, int cc) {
+      step(std::integral_constant<int, 0>{}, buf_tag, first_tag, role_tag, cc); step(std::integral_constant<int, 1>{}, buf_tag, first_tag, role_tag, cc);
+      step(std::integral_constant<int, 2>{}, buf_tag, first_tag, role_tag, cc); step(std::integral_constant<int, 3>{}, buf_tag, first_tag, role_tag, cc);
+      step(std::integral_constant<int, 4>{}, buf_tag, first_tag, role_tag, cc); step(std::integral_constant<int, 5>{}, buf_tag, first_tag, role_tag, cc);
+      step(std::integral_constant<int, 6>{}, buf_tag, first_tag, role_tag, cc); step(std::integral_constant<int, 7>{}, buf_tag, first_tag, role_tag, cc);
+      step(std::integral_constant<int, 8>{}, buf_tag, first_tag, role_tag, cc);
+    };
+    auto all_chunks = [&](auto role_tag) {
+      if constexpr (NST != 0) {                         // (chunk 0 has waits of its own only where stores are counted)
+        chunk9(std::integral_constant<int, 0>{}, std::true_type{}, role_tag, 0);
+        chunk9(std::integral_constant<int, 1>{}, std::false_type{}, role_tag, 1);
+      }
+      for (int cc = NST != 0 ? 2 : 0; cc < ncc; cc += 2) {
+        chunk9(std::integral_constant<int, 0>{}, std::false_type{}, role_tag, cc);
+        chunk9(std::integral_constant<int, 1>{}, std::false_type{}, role_tag, cc + 1);
+      }
     };
     if (tid < 8) *reinterpret_cast<uint4*>(smem + (tid >> 2) * PBUF + (PROWS - 1) * 64 + (tid & 3) * 16) = make_uint4(0, 0, 0, 0);
-    dma_patch(0, 0);
+    if (!SPEC || loader) {
+      dma_patch(0, 0);
 #pragma unroll
-    for (int j = 0; j < NS - 1; ++j) dma_b(j);
+      for (int j = 0; j < NS - 1; ++j) dma_b(j);
+    }
     __builtin_amdgcn_sched_barrier(0);                  // (the tile's first loads are on their way before the arithmetic below)
 #pragma unroll
     for (int i = 0; i < FM; ++i) {
@@ -814,23 +864,27 @@ __global__ __launch_bounds__(64 * WM * WN, (MODE == MODE_FWD3 || MODE == MODE_DG
       }
     }
     fill_pro_tables();
-    wait_vmcnt<(NS - 1) * BLD>();                       // patch 0 is older than every weight chunk
-    fix_patch(0, 0);
-    wait_vmcnt<(NS - 2) * BLD + NST>();                 // weight chunk 0 (younger: the other chunks and the pass's stores)
+    if (!SPEC || loader) {
+      wait_vmcnt<(NS - 1) * BLD>();                     // patch 0 is older than every weight chunk
+      fix_patch(0, 0);
+      wait_vmcnt<(NS - 2) * BLD + NST>();               // weight chunk 0 (younger: the other chunks and the pass's stores)
+    }
     __syncthreads();
-    read_p3(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0, std::integral_constant<int, 0>{});
+    if (!SPEC || !loader) read_p3(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, 0, std::integral_constant<int, 0>{});
     FRX_STAMP(1);
     // (the last step still waits, syncs and reads "the fragments of step nk" -- zeros from the empty descriptors: one
     // barrier too many per tile buys a loop without a tail)
-    if constexpr (NST != 0) {                           // (chunk 0 has waits of its own only where stores are counted)
-      chunk9(std::integral_constant<int, 0>{}, std::true_type{}, 0);
-      chunk9(std::integral_constant<int, 1>{}, std::false_type{}, 1);
+    if constexpr (SPEC) {
+      if (loader) {
+        all_chunks(std::integral_constant<int, 1>{});
+        wait_vmcnt<0>();
+        return;                                         // (the epilogue's barriers count the waves that are still alive)
+      }
+      all_chunks(std::integral_constant<int, 2>{});
+    } else {
+      all_chunks(std::integral_constant<int, 0>{});
+      wait_vmcnt<0>();
     }
-    for (int cc = NST != 0 ? 2 : 0; cc < ncc; cc += 2) {
-      chunk9(std::integral_constant<int, 0>{}, std::false_type{}, cc);
-      chunk9(std::integral_constant<int, 1>{}, std::false_type{}, cc + 1);
-    }
-    wait_vmcnt<0>();
   } else if constexpr (DMA) {
     // Chunk j lives in LDS stage j % NS.  Software pipeline, one barrier per chunk:
     //   step k:  wait until this wave's part of chunk k + 1 has landed (counted: the younger chunks stay in flight across

@@ -13,8 +13,21 @@ namespace frx {
     else if (bn == 128) FRX_P3(128, 128, 2, 2, MODE_, PRO_, EPI_, NS128_);                  \
     else FRX_P3(128, 64, 2, 2, MODE_, PRO_, EPI_, NS64_);                                   \
   } while (0)
+// the same tiles with staging waves (SPEC: 512 threads, one block per CU, 7 weight stages) for launches of at most 256 tiles
+#define FRX_P3S(BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_) \
+  hipLaunchKernelGGL((k_igemm<bf16_t, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, false, 64, 3, 7, false, true>), dim3(a.nvb), dim3(512), igemm_pro_lds(PRO_, a.Kc), st, a)
+#define FRX_P3S_T(MODE_, PRO_, EPI_)                                                       \
+  do {                                                                                     \
+    if (bm == 64) FRX_P3S(64, 128, 1, 4, MODE_, PRO_, EPI_);                                \
+    else FRX_P3S(128, 128, 2, 2, MODE_, PRO_, EPI_);                                        \
+  } while (0)
 int launch_igemm_p3(hipStream_t st, const ConvArgs& a, int epi, int bm, int bn) {
-  if (a.mode == MODE_FWD) {
+  const char* e = getenv("FRX_P3_SPEC");
+  const bool spec = !(e && atoi(e) == 0) && bn == 128 && (long)a.tilesM * a.tilesN <= 256;
+  if (spec && a.mode == MODE_FWD && epi == EPI_STATS) FRX_P3S_T(MODE_FWD3, 1, EPI_STATS);
+  else if (spec && a.mode == MODE_FWD && epi == EPI_PLAIN) FRX_P3S_T(MODE_FWD3, 1, EPI_PLAIN);
+  else if (spec && a.mode == MODE_DGRAD && epi == EPI_BNBWD && a.X2) FRX_P3S_T(MODE_DGRAD3, 2, EPI_BNBWD);
+  else if (a.mode == MODE_FWD) {
     if (epi == EPI_STATS) FRX_P3_T(MODE_FWD3, 1, EPI_STATS, 5, 5);
     else if (epi == EPI_PLAIN) FRX_P3_T(MODE_FWD3, 1, EPI_PLAIN, 5, 5);
     else { set_error("igemm p3 fwd: unsupported epilogue %d", epi); return FRX_ERR_ARG; }

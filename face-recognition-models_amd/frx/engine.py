@@ -162,8 +162,9 @@ class ResNet50Engine:
                 # at batch 256 35.0 vs 32.4 + 9 us, 38.2 vs 35.5 + 8; the 64-column tile (two blocks per CU next to three
                 # patch buffers) 71.7 vs 43.2 + 20 and layer4's 64-pixel tile 53.8 vs 39.6 + 7 keep the separate pass)
                 pm = ops.conv_patch_mode(c.desc, True) if (c.k == 3 and c.stride == 1) else 0
-                c.patch_dgrad = (pm == 128 and c.Ci % 128 == 0 and pm == ops._igemm_tile(c.desc, True)[0]
-                                 and os.environ.get("FRX_PATCH_DGRAD", "1") != "0")
+                sel = os.environ.get("FRX_PATCH_DGRAD", "1")      # 0: never; 2: wherever the kernel can (measurement)
+                c.patch_dgrad = (pm != 0 and pm == ops._igemm_tile(c.desc, True)[0] and sel != "0"
+                                 and (sel == "2" or (pm == 128 and c.Ci % 128 == 0)))
                 if c.k == 1 and c.stride == 2:
                     c.desc_c = ops.conv_desc(dtype, N, c.Ho, c.Ho, c.Ci, c.Co, 1, 1, 1, 0)
             if share is not None:

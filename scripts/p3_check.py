@@ -26,6 +26,7 @@ for N, H, W, Ci, Co in CASES:
     esc, esh = torch.rand(Ci, generator=g).to(DEV) + 0.5, torch.randn(Ci, generator=g).to(DEV) * 0.1
     emu, eis = torch.randn(Ci, generator=g).to(DEV) * 0.1, torch.rand(Ci, generator=g).to(DEV) + 0.5
     res = {}
+    keep = ops.conv_patch_mode(d, True) == ops._igemm_tile(d, True)[0]      # (partial rows: the side output needs the patch launch)
     for v in ("0", "1"):
         os.environ["FRX_CONV3X3"] = v
         y = torch.full((N, H, W, Co), 7.0, device=DEV, dtype=torch.bfloat16)
@@ -37,10 +38,10 @@ for N, H, W, Ci, Co in CASES:
         part2 = torch.zeros(ops.conv_dgrad_stat_rows(d) * 2 * Ci + 16, device=DEV)
         dyo = torch.full((N, H, W, Co), 7.0, device=DEV, dtype=torch.bfloat16)
         ops.conv_dgrad_bn(d, dy, wt, dx, pro_y=yy, pro_coef=coef, epi_y=ey, epi_scale=esc, epi_shift=esh, epi_mean=emu, epi_invstd=eis, epi_partial=part2,
-                          pro_dy_out=dyo if v == "1" else None)
+                          pro_dy_out=dyo if (v == "1" and keep) else None)
         torch.cuda.synchronize()
         dyref = (coef[0] * dy.float() + coef[1] * yy.float() + coef[2]).bfloat16()
-        if v == "1" and not torch.equal(dyo, dyref):
+        if v == "1" and keep and (dyo.float() - dyref.float()).abs().max().item() > 2.0 ** -7 * dyref.float().abs().max().item():
             print(f"  !! FRX_CONV3X3={v}: dy side output differs from alpha*dz + beta*y + gam: {(dyo.float() - dyref.float()).abs().max().item():.3e}"); bad += 1
         rows = ops.conv_stat_rows(d)
         st = part[: rows * 2 * Co].view(rows, 2, Co).sum(0)
