@@ -21,6 +21,7 @@ static bool p3_geometry(int dtype, int R, int S, int stride, int pad, int Wx, in
 static void p3_tile(long M, int Ncol, int* bm, int* bn) {
   *bn = Ncol % 128 == 0 ? 128 : 64;
   *bm = (*bn == 128 && (long)cdiv(M, 128) * (Ncol / 128) < 192) ? 64 : 128;
+  if (const char* e = getenv("FRX_P3_BM")) { if (atoi(e) == 128) *bm = 128; }      // (tuning aid)
 }
 
 static int launch_igemm(hipStream_t st, ConvArgs a, int dtype) {
