@@ -35,3 +35,14 @@ def nopro_all(c, x, dy, x_bn=None, pro_y=None, pro_coef=None):
 net._wgrad_job = nopro_all
 net._plan_wgrad_groups(); torch.cuda.synchronize()
 time_groups("no input prologue anywhere")
+# how much of each list is the 3x3 layers' work?  (lists re-planned WITHOUT them)
+import types
+src_plan = E.ResNet50Engine._plan_wgrad_groups if hasattr(E, "ResNet50Engine") else None
+net._wgrad_job = orig
+real_plan = ops.wgrad_group_plan
+def plan_without_3x3(dtype, jobs):
+    return real_plan(dtype, [j for j in jobs if not (j["d"].R == 3 and not j["d"].stem)])
+ops.wgrad_group_plan = plan_without_3x3
+net._plan_wgrad_groups(); torch.cuda.synchronize()
+time_groups("without the 3x3 layers' jobs")
+ops.wgrad_group_plan = real_plan
