@@ -218,3 +218,42 @@ def test_patch_swizzle_is_conflict_free_for_every_starting_row():
     assert all(lds_cycles(pswz, r0) == 4 for r0 in range(256))
     assert all(lds_cycles(swz64, r0) == 4 for r0 in range(0, 256, 16))
     assert max(lds_cycles(swz64, r0) for r0 in range(16)) == 8
+
+
+def test_patch_mode_vmcnt_counts_against_a_simulated_issue_order():
+    """conv_kernels.h, patch mode: every `s_waitcnt vmcnt(N)` of the loop is a compile-time constant derived from the ISSUE ORDER
+    of a staging thread's vector-memory operations (LDS-DMA weight chunks, patch DMAs, side-output stores: they retire in
+    issue order).  This replays that order op by op and checks, for 4..8 weight stages with and without stores and for the
+    first and the later chunks, that (1) each step's N equals the number of operations younger than the weight chunk the step
+    is about to read -- N too large would let the read pass an unlanded chunk, too small drains the ring --, and (2) the patch
+    of the next channel chunk has retired when its prologue pass runs (tap step TF = max(NS - 1, 5))."""
+    BLD, NPP = 2, 3
+
+    def formula(NS, TF, NPL, NST, t, first):
+        st = (TF < t <= TF + NS - 2) or ((not first) and t + 9 <= TF + NS - 2) or (first and t <= NS - 3)
+        return (NS - 3) * BLD + (NPL if 1 <= t <= NS - 2 else 0) + (NST if st else 0)
+
+    for NS in range(4, 9):
+        TF = max(NS - 1, 5)
+        for pro in (0, 1, 2):
+            NPL = NPP * (2 if pro == 2 else 1)
+            NST = NPP if pro else 0
+            ops = []                                   # issue order: ("D", chunk) | ("P", channel chunk) | ("S", channel chunk)
+            ops += [("P", 0)] * NPL
+            for j in range(NS - 1):
+                ops += [("D", j)] * BLD
+            ops += [("S", 0)] * NST                    # fix_patch(0, 0) in front of the loop
+            for k in range(9 * 6):
+                cc, t = divmod(k, 9)
+                last_needed = max(i for i, o in enumerate(ops) if o == ("D", k + 1))
+                younger = len(ops) - 1 - last_needed
+                n = formula(NS, TF, NPL, NST, t, cc == 0)
+                assert n == younger, (NS, pro, k, n, younger)
+                if t == TF:                            # at most n operations are outstanding now: the patch is not among them
+                    lastp = max(i for i, o in enumerate(ops) if o == ("P", cc + 1))
+                    assert len(ops) - 1 - lastp >= n, (NS, pro, k)
+                ops += [("D", k + NS - 1)] * BLD
+                if t == 0:
+                    ops += [("P", cc + 1)] * NPL
+                if t == TF:
+                    ops += [("S", cc + 1)] * NST
