@@ -258,6 +258,52 @@ def test_patch_3x3_input_gradient_vs_aten(case):
         _close(part[:, 0].sum(0), oq.sum((0, 1, 2)), 0, "patch dgrad: partial rows, sum dz")
 
 
+@pytest.mark.parametrize("case", [(256, 14, 14, 128, 128), (256, 7, 7, 256, 256), (256, 4, 4, 512, 512), (37, 28, 28, 64, 64)],
+                         ids=lambda c: "n%dh%dw%d_%dto%d" % c)
+def test_patch_3x3_is_bit_reproducible_over_many_launches(case):
+    """race screen for the patch-mode kernels (counted vmcnt waits, raw barriers, staging waves): 200 launches of the forward
+    (outputs + kept input) and of the input gradient (outputs + dy side output) on the same operands, in a stream that also
+    keeps other work in flight, must agree bit for bit with the first -- an early read of an LDS stage shows up as a rare
+    differing tile, not as a failed tolerance"""
+    from frx import ops
+    N, H, W, Ci, Co = case
+    d = ops.conv_desc(ops.BF16, N, H, W, Ci, Co, 3, 3, 1, 1)
+    x, w = _mk(1, N, H, W, Ci, seed=1).to(DEV), _mk(1, Co, 3, 3, Ci, scale=(Ci * 9) ** -0.5, seed=2).to(DEV)
+    wt = w.permute(3, 1, 2, 0).contiguous()
+    g = torch.Generator().manual_seed(3)
+    sc, sh = (torch.rand(Ci, generator=g) + 0.5).to(DEV), (torch.randn(Ci, generator=g) * 0.3).to(DEV)
+    dz, yraw = _mk(1, N, H, W, Co, seed=5).to(DEV), _mk(1, N, H, W, Co, seed=6).to(DEV)
+    coef = torch.randn(3, Co, generator=g).to(DEV)
+    ey = _mk(1, N, H, W, Ci, seed=7).to(DEV)
+    esc, esh = (torch.rand(Ci, generator=g) + 0.5).to(DEV), (torch.randn(Ci, generator=g) * 0.3).to(DEV)
+    emu, eis = (torch.randn(Ci, generator=g) * 0.2).to(DEV), (torch.rand(Ci, generator=g) + 0.5).to(DEV)
+    noise = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+
+    def fwd():
+        y = torch.empty(N, H, W, Co, dtype=torch.bfloat16, device=DEV)
+        xn = torch.empty_like(x)
+        ops.conv_fwd_keep(d, x, w, y, xn, in_scale=sc, in_shift=sh, in_relu=True)
+        return y, xn
+
+    def bwd():
+        dx = torch.empty_like(x)
+        dy = torch.empty_like(dz)
+        tot = torch.zeros(8, 2, Ci, device=DEV)
+        ops.conv_dgrad_bn(d, dz, wt, dx, pro_y=yraw, pro_coef=coef, pro_dy_out=dy, epi_y=ey, epi_scale=esc, epi_shift=esh, epi_mean=emu,
+                          epi_invstd=eis, epi_totals=tot, epi_replicas=8)
+        return dx, dy
+
+    for fn in (fwd, bwd):
+        first = [t.clone() for t in fn()]
+        bad = 0
+        for i in range(200):
+            if i % 4 == 0:
+                noise.fill_(i & 255)                   # (memory traffic of another kernel in the same stream's wake)
+            out = fn()
+            bad += sum(int(not torch.equal(a, b)) for a, b in zip(out, first))
+        assert bad == 0, f"{fn.__name__}: {bad} of 400 result tensors differ from the first launch"
+
+
 def test_patch_3x3_matches_chunk_per_tap(monkeypatch):
     """the two main loops of the same launch (FRX_CONV3X3=0: one gathered K-chunk per tap) differ only in the order of the
     fp32 accumulation: outputs agree to bf16 rounding of equal sums, statistics to 1e-5"""
