@@ -217,6 +217,12 @@ class ResNet50Engine:
         self.wgrad_stream = (torch.cuda.Stream(device=dev) if (dev.type == "cuda" and self.grouped_wgrad
                                                               and os.environ.get("FRX_WGRAD_STREAM", "0") == "1") else None)
         self.join_after_upper = True
+        # the projection branch of a layer's first block (conv + BN forward; BN-backward reduce + input / weight gradient
+        # backward) is independent of the conv1-conv2-conv3 chain until the merge / until conv1's input gradient: it runs on a
+        # side stream next to the chain (fork / join inside the captured step).  Replicated-totals mode only (the partial-rows
+        # form shares one scratch buffer between the branches).  FRX_BRANCH_STREAM=0: in line.
+        self.branch_stream = (torch.cuda.Stream(device=dev) if (dev.type == "cuda" and os.environ.get("FRX_BRANCH_STREAM", "1") != "0")
+                              else None)
         # bf16 speed mode: BatchNorm statistics travel as replicated totals the producers add into with float atomics
         # and every consumer derives its constants from (no finalize launch per layer: -104 launches per step).  The fp32
         # parity mode and FRX_BN_DETERMINISTIC=1 keep partial rows + finalize launches (bit-reproducible sums).
@@ -445,14 +451,22 @@ class ResNet50Engine:
             ops.stem_pool_fwd(dt, N, s.Ho, s.Ho, 64, s.y, self._bn(self.bn_scale, s), self._bn(self.bn_shift, s),
                               self.pool_out, self.pool_arg)
         x = self.pool_out
+        side = self.branch_stream if fused else None
         for b in self.blocks:
+            if side is not None and b.down is not None:      # projection next to the chain
+                side.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(side):
+                    self._conv_bn(b.down, x, None)
             self._conv_bn(b.conv1, x, None)
             self._conv_bn(b.conv2, b.conv1.y, b.conv1)
             self._conv_bn(b.conv3, b.conv2.y, b.conv2)
             rows = b.out.numel() // b.conv3.Co
             if fused:
                 if b.down is not None:
-                    self._conv_bn(b.down, x, None)
+                    if side is not None:
+                        torch.cuda.current_stream(self.device).wait_stream(side)
+                    else:
+                        self._conv_bn(b.down, x, None)
                 ops.block_merge_fwd_tot(dt, rows, b.conv3.Co, b.conv3.y, b.conv3.tot_f, b.down.y if b.down is not None else x,
                                         b.out, bnd=b.down.tot_f if b.down is not None else None,
                                         mask=b.mask if self.mask_bits else None)
@@ -613,6 +627,11 @@ class ResNet50Engine:
             c1, c2, c3, ds = b.conv1, b.conv2, b.conv3, b.down
             C3, C2, C1, CD = b.coefs
             dz3 = b.dz3
+            side = self.branch_stream if (self.fused_bn and ds is not None) else None
+            if side is not None:      # the projection's backward next to the conv3 / conv2 input gradients
+                side.wait_stream(torch.cuda.current_stream(self.device))
+                with torch.cuda.stream(side):
+                    proj = self._backward_projection(b, x_in, dz3, CD)
             self._finalize_bwd(c3, npart, C3)
             # conv3 (1x1): the dgrad evaluates dy3 = affine(dz3, y3) while staging its tiles and handles bn2 in its epilogue
             dz2 = self._like(S[4], c2.y)
@@ -637,23 +656,11 @@ class ResNet50Engine:
             self._finalize_bwd(c1, ops.conv_dgrad_stat_rows(c2.desc), C1)
             addend, add_stride = dz3, 0
             if ds is not None:
-                rowsd = ds.y.numel() // ds.Co
-                if self.fused_bn:
-                    ops.bn_bwd_reduce_tot(dt, rowsd, ds.Co, dz3, ds.y, self._bn(self.bn_mean, ds), self._bn(self.bn_invstd, ds),
-                                          ds.tot_b_buf, ds.R)
+                if side is not None:
+                    addend, add_stride = proj
+                    torch.cuda.current_stream(self.device).wait_stream(side)
                 else:
-                    ops.bn_bwd_reduce(dt, rowsd, ds.Co, dz3, ds.y, self._bn(self.bn_mean, ds), self._bn(self.bn_invstd, ds),
-                                      self.bwd_partial)
-                self._finalize_bwd(ds, ops.bn_bwd_partial_rows(rowsd, ds.Co), CD)
-                if ds.desc_c is not None:
-                    # stride-2 projection: only the even pixels of its input gradient are non-zero.  Compute those as a
-                    # stride-1 conv on the coarse grid ([N,Ho,Wo,Ci], a quarter of the rows) and let conv1's dgrad add
-                    # them in place, instead of a full-size GEMM whose gather is 3/4 zeros.
-                    addend = S[2][:N * ds.Ho * ds.Ho * ds.Ci].view(N, ds.Ho, ds.Ho, ds.Ci)
-                    add_stride = 2
-                else:
-                    addend = self._like(S[2], x_in)
-                self._bwd_1x1(b, ds, dz3, CD, x_in, addend)
+                    addend, add_stride = self._backward_projection(b, x_in, dz3, CD)
             # conv1 (1x1): its dgrad writes the masked output gradient of the block below (or the pool's)
             if prev is not None:      # epilogue: merge-ReLU mask of the block below + its bn3 reduce
                 self._bwd_1x1(b, c1, dz1, C1, x_in, prev.dz3, addend=addend, addend_stride=add_stride,
@@ -662,6 +669,28 @@ class ResNet50Engine:
             else:
                 self._bwd_1x1(b, c1, dz1, C1, x_in, self.g_pool, addend=addend, addend_stride=add_stride)
         self._bw_npart = npart
+
+    def _backward_projection(self, b, x_in, dz3, CD):
+        """BN-backward reduce of the projection's BatchNorm, then its input gradient (into scratch: conv1's dgrad adds it) and
+        weight gradient; returns (addend, addend_stride)"""
+        N, dt, S, ds = self.N, self.dtype, self.scratch, b.down
+        rowsd = ds.y.numel() // ds.Co
+        if self.fused_bn:
+            ops.bn_bwd_reduce_tot(dt, rowsd, ds.Co, dz3, ds.y, self._bn(self.bn_mean, ds), self._bn(self.bn_invstd, ds),
+                                  ds.tot_b_buf, ds.R)
+        else:
+            ops.bn_bwd_reduce(dt, rowsd, ds.Co, dz3, ds.y, self._bn(self.bn_mean, ds), self._bn(self.bn_invstd, ds),
+                              self.bwd_partial)
+        self._finalize_bwd(ds, ops.bn_bwd_partial_rows(rowsd, ds.Co), CD)
+        if ds.desc_c is not None:
+            # stride-2 projection: only the even pixels of its input gradient are non-zero.  Compute those as a
+            # stride-1 conv on the coarse grid ([N,Ho,Wo,Ci], a quarter of the rows) and let conv1's dgrad add
+            # them in place, instead of a full-size GEMM whose gather is 3/4 zeros.
+            addend, add_stride = S[2][:N * ds.Ho * ds.Ho * ds.Ci].view(N, ds.Ho, ds.Ho, ds.Ci), 2
+        else:
+            addend, add_stride = self._like(S[2], x_in), 0
+        self._bwd_1x1(b, ds, dz3, CD, x_in, addend)
+        return addend, add_stride
 
     @staticmethod
     def _keeps_dy(c):
