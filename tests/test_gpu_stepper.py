@@ -53,7 +53,10 @@ def test_graph_replay_equals_the_eager_step(kind):
         assert st.graphed == (i >= 1)
         # (two trajectories of an N = 8 fp32 net drift apart chaotically from the order of their fp32 atomics: the
         # comparison is tight through the first REPLAYED step and only a sanity bound afterwards)
-        assert oa["loss"].item() == pytest.approx(ob["loss"].item(), rel=1e-4 if i < 2 else 2e-2), (i, kind)
+        # (SphereFace's k = floor(m theta / pi) makes the loss a step function of the target angle: measured over 24 runs, 4 had
+        # the two trajectories 2-4 % apart at step 3 -- after agreeing to 1e-4 through the first replayed step)
+        loose = 1e-1 if kind == "sphereface" else 2e-2
+        assert oa["loss"].item() == pytest.approx(ob["loss"].item(), rel=1e-4 if i < 2 else loose), (i, kind)
         if i == 1:
             assert _rel(a.net.params, b.net.params) < 1e-3
             assert _rel(a.net.mom, b.net.mom) < 2e-2
