@@ -8,6 +8,8 @@ if os.environ.get("FRX_LIB"):          # A/B builds
     _lib.load_library(os.path.join(ROOT, os.environ["FRX_LIB"]))
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 eng = E.FaceEngine("arcface", 10575, N, dtype=ops.BF16, device="cuda:0", seed=0)
+if os.environ.get("FRX_LT_BRANCH", "0") != "1":
+    eng.net.branch_stream = None       # a launch is timed alone (the step's side stream would charge it for its neighbour)
 g = torch.Generator().manual_seed(0)
 images = (torch.rand(N, 3, 112, 112, generator=g) * 2 - 1).cuda(); labels = torch.randint(0, 10575, (N,), generator=g).cuda()
 # wrap to capture descriptors
