@@ -7,9 +7,12 @@ SGD) at 112x112, bf16, batch 256 per GPU, 10 575 identities -- BASELINE.json con
 
 One process per GPU (RCCL over xGMI via torch.distributed "nccl").  Rank 0 prints ONE JSON line.
   value        whole-job images/s, inputs resident in HBM, max-over-ranks wall time of K steps
-  roofline     the dominant kernel (by device time) timed per launch with HIP events on its own stream
-               in a separate eager pass after the timed region (the timed region replays a hipGraph,
-               which leaves no place for per-kernel events); achieved = algorithmic FLOPs / duration
+  roofline     the dominant kernel CLASS (by device time; a class = one k_igemm instantiation: tile, gather mode, prologue,
+               epilogue, staging -- frx_last_conv_launch) timed per launch with HIP events on its own stream in a separate
+               eager pass after the timed region (the timed region replays a hipGraph, which leaves no place for
+               per-kernel events); achieved = algorithmic bytes (or FLOPs) / duration; per_class lists every class
+  rccl         (N > 1) ranks that joined, each gradient bucket's all-reduce timed alone, and the time the collectives
+               leave exposed (steps with collectives - steps without)
   cpu_baseline the CPU oracle (oracle/resnet50.py, "port") on this box's host cores:
                BASELINE.json configs[0] (ArcFace R50, 100 identities, bs 32, fp32), a few steps
 """
@@ -111,6 +114,45 @@ def kernel_pass(eng, images, labels, steps=3):
         a[2] += steps
         a[3] += nbytes * steps
     return agg
+
+
+def rccl_report(stepper, step, args, ms_with, dev):
+    """Self-diagnosis of a multi-GPU run (every rank runs the same sequence; rank 0 reports): the ranks that joined, each
+    gradient bucket's all-reduce timed ALONE (barrier, then 5 back-to-back calls between two events), the step without
+    its collectives (same graph segments, collectives skipped), and what the collectives leave exposed = the difference."""
+    import torch.distributed as dist
+    eng, k = stepper.eng, min(10, max(3, args.steps))
+    out = {"ranks": dist.get_world_size(), "backend": dist.get_backend(), "bf16_buckets": bool(stepper.bf16), "allreduce_ms": {},
+           "bucket_mbytes": {}}
+    torch.cuda.synchronize()
+    for name, ranges in eng.grad_ranges().items():
+        bufs = [torch.zeros(hi - lo, device=dev, dtype=torch.bfloat16 if stepper.bf16 else torch.float32) for lo, hi in ranges]
+        for b in bufs:
+            dist.all_reduce(b)                                  # (connection set-up outside the timing)
+        dist.barrier()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            for b in bufs:
+                dist.all_reduce(b)
+        e1.record()
+        torch.cuda.synchronize()
+        out["allreduce_ms"][name] = round(e0.elapsed_time(e1) / 5, 3)
+        out["bucket_mbytes"][name] = round(sum(b.numel() * b.element_size() for b in bufs) / 1e6, 1)
+    stepper.comm_enabled = False                                # same segments, no collective issued (weights drift apart:
+    dist.barrier()                                              # measured LAST, nothing trains on them afterwards)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(k):
+        step(i)
+    torch.cuda.synchronize()
+    ms_without = (time.perf_counter() - t0) / k * 1e3
+    stepper.comm_enabled = True
+    tt = torch.tensor([ms_without], device=dev, dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    out["step_ms_without_collectives"] = round(float(tt.item()), 3)
+    out["exposed_ms"] = round(ms_with - float(tt.item()), 3)
+    return out
 
 
 def main():
@@ -244,6 +286,12 @@ def run(args):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt_s = float(tmax.item())
 
+    rccl = None
+    if world > 1 or args.split:
+        try:
+            rccl = rccl_report(stepper, step, args, dt_s / args.steps * 1e3, dev)
+        except Exception as exc:                # a diagnostic must never cost the run its result line
+            rccl = {"ranks": world, "error": repr(exc)}
     result = None
     if rank == 0:
         ips = world * args.batch * args.steps / dt_s
@@ -271,9 +319,12 @@ def run(args):
                       "mfma_tflops": round(ach_tf, 2), "mfma_frac": round(ach_tf / peak, 4),
                       "hbm_gbs": round(ach_gbs, 1), "hbm_frac": round(ach_gbs / PEAK_HBM_GBS, 4),
                       "algorithmic_bytes_per_launch": round(nbytes / launches), "algorithmic_flops_per_launch": round(flops / launches),
-                      "per_kernel": {k: {"ms_per_step": round(v[0] / 3 * 1e3, 3), "tflops": round(v[1] / v[0] / 1e12, 1),
-                                         "gbs": round(v[3] / v[0] / 1e9, 1), "launches_per_step": v[2] // 3}
-                                     for k, v in sorted(agg.items())}}
+                      # every GEMM-class behaviour of the step, largest first: where the time is and against which roof
+                      "per_class": {k: {"ms_per_step": round(v[0] / 3 * 1e3, 3), "tflops": round(v[1] / v[0] / 1e12, 1),
+                                        "tbs": round(v[3] / v[0] / 1e12, 2), "launches_per_step": v[2] // 3,
+                                        "bound": "hbm" if v[1] / v[3] < ridge else "mfma",
+                                        "frac": round((v[3] / v[0] / 1e9 / PEAK_HBM_GBS) if v[1] / v[3] < ridge else (v[1] / v[0] / 1e12 / peak), 4)}
+                                     for k, v in sorted(agg.items(), key=lambda kv: -kv[1][0])}}
             if intensity < ridge:
                 roof = {"bound": "hbm", "achieved": round(ach_gbs, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(ach_gbs / PEAK_HBM_GBS, 4), **common}
@@ -299,6 +350,8 @@ def run(args):
             "step_mfma_frac": round(ips * flop_img / (world * PEAK_BF16_TFLOPS * 1e12), 4),
             "roofline": roof, "cpu_baseline": cpu,
         }
+        if rccl is not None:
+            result["rccl"] = rccl
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

@@ -1006,6 +1006,7 @@ __global__ __launch_bounds__(256) void k_bn_finalize_batched(const int64_t* __re
     rmean[c] = (1.f - momentum) * rmean[c] + momentum * mean;
     rvar[c] = (1.f - momentum) * rvar[c] + momentum * (float)unb;
   }
+  if (row[15] && c == 0) *(int64_t*)row[15] += 1;                 // BatchNorm2d.num_batches_tracked of this layer
   for (int r = 0; r < 2 * R; ++r) tot[r * C + c] = 0.f;          // ready for the next step's adds
 }
 __global__ __launch_bounds__(256) void k_bn_bwd_finalize_batched(const int64_t* __restrict__ table, int n) {

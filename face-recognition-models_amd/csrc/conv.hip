@@ -24,7 +24,14 @@ static void p3_tile(long M, int Ncol, int* bm, int* bn) {
   if (const char* e = getenv("FRX_P3_BM")) { if (atoi(e) == 128) *bm = 128; }      // (tuning aid)
 }
 
+static thread_local int t_last_launch[12] = {0};
+void note_igemm_launch(int bm, int bn, int waves, int kc, int ns, int mode, int pro, int epi, int add, int persist, int spec) {
+  const int v[12] = {bm, bn, waves, kc, ns, mode, pro, epi, add, persist, spec, t_last_launch[11]};
+  memcpy(t_last_launch, v, sizeof(v));
+}
+
 static int launch_igemm(hipStream_t st, ConvArgs a, int dtype) {
+  t_last_launch[11] = a.R * a.S * a.Kc;                 // contraction length (note_igemm_launch fills in the rest)
   FRX_CHECK_ARG(a.Ncol % 64 == 0, "igemm: output channel count %d must be a multiple of 64", a.Ncol);
   const size_t esz = dtype == FRX_BF16 ? 2 : 4;
   const size_t xb = (size_t)a.N * a.Hx * a.Wx * (a.mode == MODE_STEM ? 4 : a.Kc) * esz;
@@ -162,6 +169,16 @@ extern "C" int frx_conv_patch_mode(const frx_conv_desc* d, int dgrad) {
   int bm, bn;
   p3_tile((long)d->N * d->Ho * d->Wo, dgrad ? d->Ci : d->Co, &bm, &bn);
   return bm;
+}
+
+// Diagnostic: the k_igemm instantiation the calling thread's last frx_conv_fwd* / frx_conv_dgrad* launched --
+// {BM, BN, waves, K-chunk bytes, LDS-DMA stages (0: register ring), MODE (0 fwd, 1 dgrad, 2 stem, 3 / 4 patch-mode 3x3 fwd /
+// dgrad), PRO (0 none, 1 BN+ReLU, 2 BN backward), EPI (0 plain, 1 statistics, 2 / 4 masked BN-backward statistics, 3 fc),
+// addend, persistent, staging waves, contraction length}: what bench.py's per-class roofline table is keyed by.
+extern "C" int frx_last_conv_launch(int* fields12) {
+  FRX_CHECK_ARG(fields12 != nullptr, "last_conv_launch: NULL pointer");
+  memcpy(fields12, t_last_launch, sizeof(t_last_launch));
+  return FRX_OK;
 }
 
 extern "C" int frx_stem_padded_dims(int Hi, int Wi, int* Hp, int* Wp) {

@@ -283,13 +283,15 @@ static inline unsigned igemm_pro_lds(int pro, int Kc) { return pro ? (pro == 2 ?
 // MODE (gather geometry) and PRO (BN+ReLU prologue) are compile-time so the steady-state K loop is
 // straight-line code: hipcc then keeps counted s_waitcnt vmcnt(N) for the register ring.
 template <typename T, int BM, int BN, int WM, int WN, int MODE, int PRO, int EPI, bool ADD, int KC = 64, int PD = 3, int NS = 0, bool PERSIST = false, bool SPEC = false>   // PRO: 0 none, 1 BN+ReLU, 2 BN-backward affine; KC: bytes of the contraction axis per row and K-chunk; PD: ring depth; NS > 0: LDS-DMA staging into a ring of NS LDS stages (PRO == 0 only) instead of the register ring
+// (patch mode: three blocks per CU on the 64-column tile -- except its BN-backward-prologue input gradient, which spilled 13
+// registers at 168 and must not: scratch accesses count in the hand-counted vmcnt; csrc/check_spills.py fails the build on any)
 // waves per SIMD the register budget must allow: 3 where the kernel fits 168 registers without spilling (measured:
 // +10-20 % on the prologue-free variants), 2 for the BN-prologue variants (they spill 35-50 registers at 3)
 // (WM x WN = 4 waves; or 8 waves on a 128x128 tile for launches with too few tiles to give every SIMD two waves)
 #ifndef FRX_OCC4W            // tuning aid: blocks per CU the four-wave tiles are compiled for (0: the table below)
 #define FRX_OCC4W 0
 #endif
-__global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1), SPEC ? 1 : (MODE == MODE_FWD3 || MODE == MODE_DGRAD3) ? (BN == 64 ? 3 : 2) : (NS > 4) ? (WM * WN) / 4 : (KC == 128 || PD > 3) ? 2 : (WM * WN == 8 ? 4 : (FRX_OCC4W ? FRX_OCC4W : ((PRO == 0 && EPI != EPI_BNBWD_OUT && !ADD) ? 3 : 2)))) void k_igemm(ConvArgs ka) {
+__global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1), SPEC ? 1 : (MODE == MODE_FWD3 || MODE == MODE_DGRAD3) ? ((BN == 64 && !(MODE == MODE_DGRAD3 && PRO == 2)) ? 3 : 2) : (NS > 4) ? (WM * WN) / 4 : (KC == 128 || PD > 3) ? 2 : (WM * WN == 8 ? 4 : (FRX_OCC4W ? FRX_OCC4W : ((PRO == 0 && EPI != EPI_BNBWD_OUT && !ADD) ? 3 : 2)))) void k_igemm(ConvArgs ka) {
   // P3 (MODE_FWD3 / MODE_DGRAD3): 3x3, stride 1, pad 1.  The rows a tile gathers over its nine taps are the CONTIGUOUS pixel
   // range [m0 - W - 1, m0 + BM + W + 1) of the flattened (n, h, w) axis, so per 64-byte channel chunk that range is staged
   // ONCE as a patch (LDS-DMA, then the BN prologue in place on the staging thread's own 16-byte pieces) and the nine taps
@@ -1152,7 +1154,9 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1), SPEC ? 1 : (MODE == 
     run_tile(ka, blockIdx.x);
   }
   if constexpr (STATS_) {
-    if (ka.stat_tot && tid_ < 2 * BN)      // replica = block index mod R (the XCD id for R = 8: as spread as the row-tile index)
+    // (launch_igemm guarantees Ncol % BN == 0, so columns n0_blk .. n0_blk + BN - 1 exist; a padding block -- its virtual
+    // tile lies past tilesM, `first_tile` still set -- has nothing to add)
+    if (ka.stat_tot && tid_ < 2 * BN && !first_tile)      // replica = block index mod R (the XCD id for R = 8: as spread as the row-tile index)
       __hip_atomic_fetch_add(ka.stat_tot + ((long)(blockIdx.x % ka.stat_R) * 2 + tid_ / BN) * ka.Ncol + n0_blk + tid_ % BN, stat_run,
                              __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }

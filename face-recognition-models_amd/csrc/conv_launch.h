@@ -77,8 +77,12 @@ int launch_wgrad(hipStream_t st, const WgradArgs& a, int dtype, int bt, int wmod
 int launch_wgrad_grouped(hipStream_t st, int dtype, const WgradArgs* layers, const WgradItem* items, int nitems, bool small_tiles,
                          int* draw_counters);
 
+// diagnostic (frx_last_conv_launch): the template arguments of the k_igemm instantiation this thread launched last
+void note_igemm_launch(int bm, int bn, int waves, int kc, int ns, int mode, int pro, int epi, int add, int persist, int spec);
+
 #define FRX_IGEMM_KNP(T_, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, ADD_, KC_, NS_, PERSIST_) \
-  hipLaunchKernelGGL((k_igemm<T_, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, ADD_, KC_, 3, NS_, PERSIST_>), dim3(PERSIST_ ? grid : a.nvb), dim3(64 * WM_ * WN_), igemm_pro_lds(PRO_, a.Kc), st, a)
+  do { note_igemm_launch(BM_, BN_, WM_ * WN_, KC_, NS_, MODE_, PRO_, EPI_, ADD_, PERSIST_, 0); \
+  hipLaunchKernelGGL((k_igemm<T_, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, ADD_, KC_, 3, NS_, PERSIST_>), dim3(PERSIST_ ? grid : a.nvb), dim3(64 * WM_ * WN_), igemm_pro_lds(PRO_, a.Kc), st, a); } while (0)
 #define FRX_IGEMM_KN(T_, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, ADD_, KC_, NS_) FRX_IGEMM_KNP(T_, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, ADD_, KC_, NS_, false)
 #define FRX_IGEMM_K(T_, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, ADD_, KC_) FRX_IGEMM_KN(T_, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, ADD_, KC_, 0)
 #define FRX_IGEMM_LAUNCH64(T_, MODE_, PRO_, EPI_, ADD_)                                                                    \

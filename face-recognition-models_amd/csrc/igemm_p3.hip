@@ -3,7 +3,8 @@
 #include "conv_launch.h"
 namespace frx {
 #define FRX_P3(BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, NS_) \
-  hipLaunchKernelGGL((k_igemm<bf16_t, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, false, 64, 3, NS_, false>), dim3(a.nvb), dim3(256), igemm_pro_lds(PRO_, a.Kc), st, a)
+  do { note_igemm_launch(BM_, BN_, WM_ * WN_, 64, NS_, MODE_, PRO_, EPI_, 0, 0, 0); \
+  hipLaunchKernelGGL((k_igemm<bf16_t, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, false, 64, 3, NS_, false>), dim3(a.nvb), dim3(256), igemm_pro_lds(PRO_, a.Kc), st, a); } while (0)
 // tiles: 128 x 128 and 128 x 64 on 2 x 2 waves; 64 x 128 on 1 x 4 waves for launches that would otherwise leave CUs without a
 // tile (layer4: 4096 pixels).  Weight stages: what two blocks per CU -- three on the 64-column tile -- leave of the 160 KB
 // next to the patch buffers.
@@ -15,7 +16,8 @@ namespace frx {
   } while (0)
 // the same tiles with staging waves (SPEC: 512 threads, one block per CU, 7 weight stages) for launches of at most 256 tiles
 #define FRX_P3S(BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_) \
-  hipLaunchKernelGGL((k_igemm<bf16_t, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, false, 64, 3, 7, false, true>), dim3(a.nvb), dim3(512), igemm_pro_lds(PRO_, a.Kc), st, a)
+  do { note_igemm_launch(BM_, BN_, WM_ * WN_, 64, 7, MODE_, PRO_, EPI_, 0, 0, 1); \
+  hipLaunchKernelGGL((k_igemm<bf16_t, BM_, BN_, WM_, WN_, MODE_, PRO_, EPI_, false, 64, 3, 7, false, true>), dim3(a.nvb), dim3(512), igemm_pro_lds(PRO_, a.Kc), st, a); } while (0)
 #define FRX_P3S_T(MODE_, PRO_, EPI_)                                                       \
   do {                                                                                     \
     if (bm == 64) FRX_P3S(64, 128, 1, 4, MODE_, PRO_, EPI_);                                \

@@ -89,6 +89,7 @@ _SIGS = {
     "frx_conv_wgrad": (C.c_int, [C.c_int, _P, C.POINTER(ConvDesc), _P, _P, _P, C.c_int, _P, _P]),
     "frx_conv_dgrad_stat_rows": (C.c_int, [C.POINTER(ConvDesc)]),
     "frx_conv_tile": (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "frx_last_conv_launch": (C.c_int, [C.POINTER(C.c_int)]),
     "frx_conv_patch_mode": (C.c_int, [C.POINTER(ConvDesc), C.c_int]),
     "frx_wgrad_group_bytes": (C.c_int64, [C.POINTER(WgradJob), C.c_int]),
     "frx_wgrad_group_plan": (C.c_int, [C.c_int, _P, C.POINTER(WgradJob), C.c_int, _P, _P, C.c_int64, C.POINTER(C.c_int),
@@ -117,6 +118,8 @@ _SIGS = {
     "frx_sgd_step": (C.c_int, [C.c_int, _P, C.c_int64, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float, C.c_float]),
     "frx_weight_prep": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, _P, _P]),
     "frx_weight_prep_batched": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, _P, _P, C.c_int]),
+    "frx_sgd_step_prep": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, _P, C.c_int, _P, _P, _P, _P, C.c_float, C.c_float, C.c_float,
+                                    C.c_float, C.c_int]),
     "frx_input_prep": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int, C.c_int, _P, C.c_int, _P, C.c_int64]),
     "frx_cast": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, C.c_int64, _P, _P]),
     "frx_colsum_f32": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, _P, _P]),

@@ -67,8 +67,8 @@ class DataParallelStep:
         # of their own for them (class-sharded heads have no head gradient on the wire: they keep the two-bucket plan)
         self.head_bucket = (self.multi and hasattr(engine, "stage_head") and hasattr(engine, "stage_upper_rest")
                             and getattr(engine, "shard", None) is None)
-        if self.head_bucket and hasattr(engine, "set_head_bucket"):
-            engine.set_head_bucket(True)
+        if hasattr(engine, "set_head_bucket"):       # (sticky engine state: a single-GPU stepper on the same engine resets it;
+            engine.set_head_bucket(self.head_bucket)  # both flags are part of the engine's graph_key())
         # one graph for the whole step: the upper weight-gradient list may still run (side stream, FRX_WGRAD_STREAM=1) while
         # the lower backward proceeds; with buckets its gradients must be final where the "upper" segment ends
         net = getattr(engine, "net", None)
@@ -82,6 +82,7 @@ class DataParallelStep:
         self._warm = False
         self._out = None
         self._pending = []
+        self.comm_enabled = True       # False: the segments run, their collectives are skipped (bench.py: exposed-time measurement)
         if self.bf16:
             self._pack = {k: [torch.empty(hi - lo, dtype=torch.bfloat16, device=engine.device) for lo, hi in v]
                           for k, v in engine.grad_ranges().items()}
@@ -126,6 +127,8 @@ class DataParallelStep:
         return [[name for name, _, _ in items] for items in self._segment_items()]
 
     def _comm_ty(self):                     # CurricularFace: global sum of the target cosines (criterion.py:570-573)
+        if not self.comm_enabled:
+            return
         dist.all_reduce(self.eng.ty_sum, op=dist.ReduceOp.SUM, group=self.group)
 
     def _comm_head(self):                   # head + fc gradients: on the wire while layer4 / layer3 run their backward
@@ -144,6 +147,8 @@ class DataParallelStep:
         """start the SUM all-reduce of one set of gradient ranges; returns the handles to finish()"""
         flat = self.eng.flat_grads
         handles = []
+        if not self.comm_enabled:
+            return handles
         for i, (lo, hi) in enumerate(self.eng.grad_ranges()[which]):
             if self.bf16:
                 buf = self._pack[which][i]

@@ -184,14 +184,8 @@ class ResNet50Engine:
         for b in self.blocks:
             b.out = torch.zeros_like(b.conv3.y)
             b.mask = torch.zeros(b.out.numel() // (8 if dtype == BF16 else 4), dtype=torch.uint8, device=dev)
-            b.dz3 = torch.zeros_like(b.conv3.y)
-            b.dy2 = torch.zeros_like(b.conv2.y)
-            c2 = b.conv2
-            pm = ops.conv_patch_mode(c2.desc, False) if (c2.k == 3 and c2.stride == 1) else 0
-            if pm and pm == ops._igemm_tile(c2.desc)[0] and os.environ.get("FRX_KEEP_XNORM", "1") != "0":
-                c2.x_norm = torch.zeros_like(b.conv1.y)      # (+180 MB at batch 256; the grouped lists: -78 us per step)
-            b.dyc = {c.name: torch.zeros_like(c.y) for c in (b.conv1, b.conv3, b.down) if c is not None and self._keeps_dy(c)}
             b.coefs = [torch.zeros(3 * c.Co, device=dev) if c is not None else None for c in (b.conv3, b.conv2, b.conv1, b.down)]
+        self._train_ready = False       # the backward's per-block buffers: allocated by the first TRAINING forward (_ensure_training_buffers)
         self.pooled = torch.zeros(N, 2048, dtype=self.tdt, device=dev)
         self.feats = torch.zeros(N, FEATURE_DIM, device=dev)
         self.fc_desc = ops.conv_desc(dtype, N, 1, 1, 2048, FEATURE_DIM, 1, 1, 1, 0)
@@ -239,8 +233,29 @@ class ResNet50Engine:
         self.share = share
         if share is None:
             self.reset_parameters()
+
+    def _ensure_training_buffers(self):
+        """Per-block buffers only a training step touches -- the masked output gradient, conv2's dy, the kept dy copies and
+        the kept relu(bn(x)) input of each patch-mode conv2 (+300 MB at batch 256, linear in the batch) -- and the
+        weight-gradient work lists that point at them.  Built by the first training forward (an eager call: the plan's
+        host->device copy must not land inside a graph capture); embedding-only engines (the B = 512 engine of the LFW path,
+        weight-sharing plans of other batch sizes that never train) never pay for them."""
+        if self._train_ready:
+            return
+        if self.device.type == "cuda" and torch.cuda.is_current_stream_capturing():
+            raise ops.FrxError("the first training forward of an engine allocates its backward buffers: run one eager step "
+                               "before capturing a graph")
+        for b in self.blocks:
+            b.dz3 = torch.zeros_like(b.conv3.y)
+            b.dy2 = torch.zeros_like(b.conv2.y)
+            c2 = b.conv2
+            pm = ops.conv_patch_mode(c2.desc, False) if (c2.k == 3 and c2.stride == 1) else 0
+            if pm and pm == ops._igemm_tile(c2.desc)[0] and os.environ.get("FRX_KEEP_XNORM", "1") != "0":
+                c2.x_norm = torch.zeros_like(b.conv1.y)      # (the grouped lists: -78 us per step)
+            b.dyc = {c.name: torch.zeros_like(c.y) for c in (b.conv1, b.conv3, b.down) if c is not None and self._keeps_dy(c)}
+        self._train_ready = True
         if self.grouped_wgrad:
-            self._plan_wgrad_groups()          # here, not at first use: the plan's host->device copy must not land inside a graph capture
+            self._plan_wgrad_groups()
 
     # ------------------------------------------------------------------ BatchNorm statistics as replicated totals
     def _plan_bn_totals(self):
@@ -278,7 +293,7 @@ class ResNet50Engine:
                                  self._bn(self.running_mean, c).data_ptr(), self._bn(self.running_var, c).data_ptr(),
                                  self._bn(self.bn_mean, c).data_ptr(), self._bn(self.bn_invstd, c).data_ptr(),
                                  self._bn(self.bn_scale, c).data_ptr(), self._bn(self.bn_shift, c).data_ptr(), blk,
-                                 f2i(BN_EPS), f2i(BN_MOMENTUM), 0))
+                                 f2i(BN_EPS), f2i(BN_MOMENTUM), self.num_batches_tracked[c.bn_idx:c.bn_idx + 1].data_ptr()))
                 else:
                     rows.append((c.tot_b_buf.data_ptr(), c.R, c.Co, count, self.gamma(c).data_ptr(),
                                  self._bn(self.bn_mean, c).data_ptr(), self._bn(self.bn_invstd, c).data_ptr(),
@@ -364,8 +379,17 @@ class ResNet50Engine:
                 blk += (c.Co // 64) * (c.Ci // 64) * c.k * c.k
         rows.append((self.fc_w_off, FEATURE_DIM, 1, 2048, self.fc_wk.data_ptr(), self.fc_wt.data_ptr(), blk, 1))
         blk += (FEATURE_DIM // 64) * (2048 // 64)
+        self._prep_rows, self._prep_blocks = len(rows), blk
+        # the fused optimiser launch (frx_sgd_step_prep) walks the same table plus the ranges that have no kernel-format copy:
+        # BatchNorm gamma / beta, then fc bias + padding + the margin head
+        first_g = self.convs[0].g_off
+        for lo, hi in ((first_g, self.fc_w_off), (self.fc_b_off, self.n_params)):
+            assert lo % 4 == 0 and (hi - lo) % 4 == 0
+            rows.append((lo, hi - lo, 0, 0, 0, 0, blk, 2))
+            blk += (hi - lo + 1023) // 1024
+        assert self.convs[-1].w_off + self.convs[-1].w_numel == first_g
         self._prep_table = torch.tensor(rows, dtype=torch.int64, device=self.device)
-        self._prep_blocks = blk
+        self._sgd_blocks = blk
 
     def sync_weights(self, pad=True):
         """fp32 master -> kernel-format copies (after an optimiser step or a state-dict load): one launch.
@@ -377,7 +401,10 @@ class ResNet50Engine:
             m[..., 3] = 0
         if getattr(self, "_prep_table", None) is None:
             self._build_prep_table()
-        ops.weight_prep_batched(self.dtype, self._prep_table, self.params, self._prep_blocks)
+        ops.weight_prep_batched(self.dtype, self._prep_table[:self._prep_rows], self.params, self._prep_blocks)
+        self._bump_weights_version()
+
+    def _bump_weights_version(self):
         owner = self.share or self
         owner.weights_version = getattr(owner, "weights_version", 0) + 1
 
@@ -437,7 +464,9 @@ class ResNet50Engine:
                 self._prepare_eval_affine()
                 self._eval_affine_ready = stamp
         if self.training:
-            self.num_batches_tracked += 1
+            self._ensure_training_buffers()
+            if not self.fused_bn:       # (replicated totals: frx_bn_finalize_batched bumps the counters, no launch of its own)
+                self.num_batches_tracked += 1
             owner = self.share or self
             owner.stats_version = getattr(owner, "stats_version", 0) + 1
             self._eval_affine_ready = False
@@ -565,6 +594,7 @@ class ResNet50Engine:
         """the fc layer's backward: its weight / bias gradients are final afterwards (with `head_bucket` its weight gradient
         is a launch of its own instead of a job of the upper grouped list, so that the bucket can leave early)"""
         dt, S = self.dtype, self.scratch
+        (self.share or self)._grads_clean = False
         ops.cast(dt, dfeat, self.dfeat_t, to_f32=False)
         if not self.grouped_wgrad or getattr(self, "head_bucket", False):   # (grouped: one more job of the upper list --
             ops.conv_wgrad(self.fc_desc, self.pooled, self.dfeat_t, self.fc_w(self.grads))     # its own launch costs 34 us for 64 tiles)
@@ -788,8 +818,9 @@ class ResNet50Engine:
         on = bool(on)
         if on != getattr(self, "head_bucket", False):
             self.head_bucket = on
-            if self.grouped_wgrad:
+            if self.grouped_wgrad and self._train_ready:
                 torch.cuda.synchronize(self.device)
+                self._old_wg_groups = self._wg_groups      # (a graph captured under the other setting may still name these tables)
                 self._plan_wgrad_groups()
 
     def _run_wgrad_group(self, which):
@@ -815,12 +846,26 @@ class ResNet50Engine:
     # ------------------------------------------------------------------ optimiser
     def zero_grad(self):
         self.grads.zero_()
+        (self.share or self)._grads_clean = True
 
-    def sgd_step(self, lr=None, momentum=0.9, weight_decay=5e-4, grad_scale=1.0):
-        """lr=None: read the learning rate from self.lr_dev (graph-replay friendly)."""
-        ops.sgd_step(self.params, self.grads, self.mom, 0.0 if lr is None else lr, momentum, weight_decay, grad_scale,
-                     lr_dev=self.lr_dev if lr is None else None)
-        self.sync_weights(pad=False)
+    def ensure_zero_grad(self):
+        """optimizer.zero_grad() of model_utils.py:184 for the fused step: a launch only when the gradient buffer is not
+        already zero (sgd_step() zeroes it as it consumes it)"""
+        if not getattr(self.share or self, "_grads_clean", False):
+            self.zero_grad()
+        (self.share or self)._grads_clean = False            # the backward that follows accumulates into it
+
+    def sgd_step(self, lr=None, momentum=0.9, weight_decay=5e-4, grad_scale=1.0, zero_grads=True):
+        """lr=None: read the learning rate from self.lr_dev (graph-replay friendly).  ONE launch: SGD on the flat fp32
+        buffers, the kernel-format (KRSC / CRSK) copies of the updated conv / fc weights, and -- zero_grads -- the zero-fill
+        of the gradient buffer the next step accumulates into (model_utils.py:184-187)."""
+        if getattr(self, "_prep_table", None) is None:
+            self._build_prep_table()
+        ops.sgd_step_prep(self.dtype, self._prep_table, self._sgd_blocks, self.params, self.grads, self.mom,
+                          0.0 if lr is None else lr, momentum, weight_decay, grad_scale,
+                          lr_dev=self.lr_dev if lr is None else None, zero_grads=zero_grads)
+        (self.share or self)._grads_clean = bool(zero_grads)
+        self._bump_weights_version()
 
     # ------------------------------------------------------------------ torchvision-compatible state dict
     def state_dict(self, prefix=""):
@@ -1071,7 +1116,8 @@ class FaceEngine:
     def graph_key(self):
         """host-side values a captured launch carries BY VALUE: when one changes the graphs are captured again"""
         return (self.head.desc.flags & ~4, self.head.desc.lamb if self.kind == ops.MAG else 0.0,
-                self.sgd_momentum, self.sgd_weight_decay, self.world)
+                self.sgd_momentum, self.sgd_weight_decay, self.world,
+                bool(getattr(self.net, "head_bucket", False)), bool(self.net.join_after_upper))
 
     def pre_step(self):
         """host-side work of a step that stays outside the captured graphs"""
@@ -1088,7 +1134,7 @@ class FaceEngine:
 
     def stage_forward(self, images, labels):
         self.net.training = True
-        self.net.zero_grad()
+        self.net.ensure_zero_grad()
         feats = self.net.forward(images)
         ops.head_forward_cos(self.head, feats, self.head_w(), labels, state_t=self.t, ty_sum=self.ty_sum)
 
@@ -1119,7 +1165,7 @@ class FaceEngine:
     # ---- class-sharded head: the compute between the collectives of frx/ddp.py: sharded_plan
     def shard_stage_backbone(self, images, labels):
         self.net.training = True
-        self.net.zero_grad()
+        self.net.ensure_zero_grad()
         self.net.forward(images)
         self.feats_l = self.net.feats
         self.labels_l.copy_(labels)
@@ -1167,7 +1213,7 @@ class FaceEngine:
     def train_step(self, images, labels, lr=None):
         """zero_grad -> forward -> CE -> backward -> [all-reduce] -> SGD (model_utils.py:176-187), eagerly."""
         self.net.training = True
-        self.net.zero_grad()
+        self.net.ensure_zero_grad()
         out = self.forward_loss(images, labels)
         self.backward(labels)
         if self.allreduce is not None:

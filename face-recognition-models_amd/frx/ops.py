@@ -28,8 +28,30 @@ def _timed(label, flops, dev_tensor, fn, nbytes=0):
     e0.record(st)
     r = fn()
     e1.record(st)
-    PROFILER.append((label, flops, e0, e1, nbytes))
+    PROFILER.append((label() if callable(label) else label, flops, e0, e1, nbytes))
     return r
+
+
+_MODE = {0: "fwd", 1: "dgrad", 2: "stem", 3: "fwd3x3patch", 4: "dgrad3x3patch"}
+_PRO = {0: "none", 1: "bn_relu", 2: "bn_bwd"}
+_EPI = {0: "plain", 1: "stats", 2: "bnbwd_stats", 3: "fc", 4: "bnbwd_stats_maskout"}
+
+
+def igemm_class(dtype_name, f):
+    """label of ONE k_igemm behaviour from frx_last_conv_launch's fields (the same string scripts/traffic_summary.py
+    derives from the kernel symbol): tile, gather mode, prologue, epilogue, staging"""
+    bm, bn, waves, kc, ns, mode, pro, epi, add, persist, spec = f[:11]
+    stage = "patch" if mode in (3, 4) else (f"dma{ns}" if ns else "ring")
+    return (f"k_igemm<{dtype_name},{bm}x{bn}x{waves}w,kc{kc},{_MODE[mode]},pro={_PRO[pro]},epi={_EPI[epi]}{'+add' if add else ''},"
+            f"{stage}{',persist' if persist else ''}{',stagewaves' if spec else ''}>")
+
+
+def _igemm_label(dtype):
+    def get():
+        f = (C.c_int * 12)()
+        check(_lib.lib().frx_last_conv_launch(f), "frx_last_conv_launch")
+        return igemm_class(_dt_name(dtype), list(f))
+    return get
 
 
 def _igemm_tile(d, dgrad=False):
@@ -311,8 +333,7 @@ def conv_flops(d):
 
 
 def conv_fwd(d, x, w, y, in_scale=None, in_shift=None, in_relu=False, bias=None, out_f32=False, stat_partial=None):
-    bm, bn = _igemm_tile(d) if PROFILER is not None else (0, 0)
-    _timed(f"k_igemm<{_dt_name(d.dtype)},{bm},{bn}>", conv_flops(d), x, lambda: check(
+    _timed(_igemm_label(d.dtype), conv_flops(d), x, lambda: check(
         _lib.lib().frx_conv_fwd(_dev(x), _stream(x), C.byref(d), _p(x), _p(w), _p(in_scale), _p(in_shift),
                                 int(in_relu), _p(bias), _p(y), int(out_f32), _p(stat_partial)), "frx_conv_fwd"),
         nbytes=conv_bytes(d))
@@ -326,8 +347,7 @@ def bn_tot(totals, replicas, count, gamma, beta=None, mean=None, invstd=None, ep
 
 def conv_fwd_tot(d, x, w, y, in_bn=None, in_relu=True, stat_totals=None, stat_replicas=0):
     """conv_fwd with the prologue constants derived from `in_bn` (a BnTot) and the statistics of y added into stat_totals"""
-    bm, bn = _igemm_tile(d) if PROFILER is not None else (0, 0)
-    _timed(f"k_igemm<{_dt_name(d.dtype)},{bm},{bn}>", conv_flops(d), x, lambda: check(
+    _timed(_igemm_label(d.dtype), conv_flops(d), x, lambda: check(
         _lib.lib().frx_conv_fwd_tot(_dev(x), _stream(x), C.byref(d), _p(x), _p(w), C.byref(in_bn) if in_bn is not None else None,
                                     int(in_relu), _p(y), _p(stat_totals), int(stat_replicas)), "frx_conv_fwd_tot"),
         nbytes=conv_bytes(d))
@@ -337,8 +357,7 @@ def conv_fwd_tot(d, x, w, y, in_bn=None, in_relu=True, stat_totals=None, stat_re
 def conv_fwd_keep(d, x, w, y, x_norm_out, in_scale=None, in_shift=None, in_bn=None, in_relu=True, stat_partial=None,
                   stat_totals=None, stat_replicas=0):
     """frx_conv_fwd_keep: the forward of a patch-mode 3x3 layer that also stores its prologue's output relu(bn(x))"""
-    bm, bn = _igemm_tile(d) if PROFILER is not None else (0, 0)
-    _timed(f"k_igemm<{_dt_name(d.dtype)},{bm},{bn}>", conv_flops(d), x, lambda: check(
+    _timed(_igemm_label(d.dtype), conv_flops(d), x, lambda: check(
         _lib.lib().frx_conv_fwd_keep(_dev(x), _stream(x), C.byref(d), _p(x), _p(w), _p(in_scale), _p(in_shift),
                                      C.byref(in_bn) if in_bn is not None else None, int(in_relu), _p(y), _p(stat_partial),
                                      _p(stat_totals), int(stat_replicas), _p(x_norm_out)), "frx_conv_fwd_keep"),
@@ -347,8 +366,7 @@ def conv_fwd_keep(d, x, w, y, x_norm_out, in_scale=None, in_shift=None, in_bn=No
 
 
 def conv_dgrad(d, dy, w_crsk, dx, addend=None):
-    bm, bn = _igemm_tile(d, True) if PROFILER is not None else (0, 0)
-    _timed(f"k_igemm<{_dt_name(d.dtype)},{bm},{bn}>", conv_flops(d), dy, lambda: check(
+    _timed(_igemm_label(d.dtype), conv_flops(d), dy, lambda: check(
         _lib.lib().frx_conv_dgrad(_dev(dy), _stream(dy), C.byref(d), _p(dy), _p(w_crsk), _p(addend), _p(dx)),
         "frx_conv_dgrad"), nbytes=conv_bytes(d, n_in=1 + (addend is not None)))
     return dx
@@ -419,8 +437,7 @@ def conv_dgrad_bn(d, dz, w_crsk, dx, addend=None, pro_y=None, pro_coef=None, epi
                        int(addend_stride), 0 if pro_dy_out is None else pro_dy_out.data_ptr(),
                        C.pointer(pro_tot) if pro_tot is not None else None,
                        0 if epi_totals is None else epi_totals.data_ptr(), int(epi_replicas))
-    bm, bn = _igemm_tile(d, True) if PROFILER is not None else (0, 0)
-    _timed(f"k_igemm<{_dt_name(d.dtype)},{bm},{bn}>", conv_flops(d), dz, lambda: check(
+    _timed(_igemm_label(d.dtype), conv_flops(d), dz, lambda: check(
         _lib.lib().frx_conv_dgrad_bn(_dev(dz), _stream(dz), C.byref(d), _p(dz), _p(w_crsk), _p(addend), _p(dx),
                                      C.byref(f)), "frx_conv_dgrad_bn"),
         nbytes=conv_bytes(d, n_in=1 + (addend is not None) + (epi_y is not None) + (epi_out is not None) + (epi_out_bits is not None) / 16,
@@ -562,6 +579,14 @@ def avgpool_bwd(dtype, N, HW, Cc, dpool, dx):
 def sgd_step(p, g, buf, lr, momentum=0.9, weight_decay=5e-4, grad_scale=1.0, lr_dev=None):
     check(_lib.lib().frx_sgd_step(_dev(p), _stream(p), p.numel(), _p(p), _p(g), _p(buf), _p(lr_dev), float(lr),
                                   float(momentum), float(weight_decay), float(grad_scale)), "frx_sgd_step")
+
+
+def sgd_step_prep(dtype, table, total_blocks, p, g, buf, lr, momentum=0.9, weight_decay=5e-4, grad_scale=1.0, lr_dev=None,
+                  zero_grads=True):
+    """SGD + kernel-format weight copies (+ the gradient zero-fill) in one launch (include/frx.h: frx_sgd_step_prep)"""
+    check(_lib.lib().frx_sgd_step_prep(_dev(p), _stream(p), dtype, table.shape[0], _p(table), total_blocks, _p(p), _p(g), _p(buf),
+                                       _p(lr_dev), float(lr), float(momentum), float(weight_decay), float(grad_scale),
+                                       1 if zero_grads else 0), "frx_sgd_step_prep")
 
 
 def weight_prep(dtype, Co, RS, Ci, master, krsc=None, crsk=None):

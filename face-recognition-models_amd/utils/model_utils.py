@@ -85,7 +85,8 @@ class FusedSGD(torch.optim.Optimizer):
         eng = self._engine()
         g = self.param_groups[0]
         self._apply_pending(eng)
-        eng.net.sgd_step(g["lr"], g["momentum"], g["weight_decay"])
+        # (torch semantics: .grad survives optimizer.step(); the step driver's own update zeroes it instead of a fill launch)
+        eng.net.sgd_step(g["lr"], g["momentum"], g["weight_decay"], zero_grads=False)
         self.model._synced_version = self.model._version_sum()
 
     # checkpoints: momentum lives in the engine's flat buffer; it is saved and loaded in torch.optim.SGD's OWN format

@@ -206,6 +206,12 @@ int frx_conv_tile(const frx_conv_desc* d, int dgrad, int* bm, int* bn);
  * no addend -- and, if it asks for per-tile partial statistics, frx_conv_tile's row tile is the same.  0 otherwise; -1
  * for a rejected descriptor.  FRX_CONV3X3=0 in the environment switches the kernel off. */
 int frx_conv_patch_mode(const frx_conv_desc* d, int dgrad);
+/* diagnostic (host logic only): the implicit-GEMM kernel instantiation the calling thread's last frx_conv_fwd* /
+ * frx_conv_dgrad* call launched: fields12 = {BM, BN, waves, K-chunk bytes, LDS-DMA stages (0 = register ring), MODE (0 fwd,
+ * 1 dgrad, 2 stem, 3 / 4 patch-mode 3x3 forward / input gradient), PRO (0 none, 1 BN+ReLU, 2 BN backward), EPI (0 plain,
+ * 1 statistics, 2 / 4 masked BN-backward statistics, 3 fc), addend, persistent, staging waves, contraction length} --
+ * the key of bench.py's per-class roofline table and of scripts/traffic_summary.py's PMC rows */
+int frx_last_conv_launch(int* fields12);
 int frx_stem_padded_dims(int Hi, int Wi, int* Hp, int* Wp);
 /* Train-mode BatchNorm statistics as REPLICATED TOTALS (csrc/bn_tot.h; replaces the 53 + 53 per-layer finalize launches of
  * a training step, i.e. the statistics half of every nn.BatchNorm2d forward / backward of backbones.py:16-18).  A producing
@@ -329,7 +335,8 @@ int frx_block_merge_fwd_tot(int device, frx_stream_t stream, int dtype, int64_t 
 /* every listed BatchNorm layer in ONE launch (one thread per channel): totals -> mean / invstd / scale / shift (+ running
  * statistics), then the rows are zeroed.  table_dev [n][16] int64 = {totals, replicas, C, count, gamma, beta,
  * running_mean | 0, running_var | 0, mean, invstd, scale, shift, index of the layer's first block (256 channels per
- * block), eps as float bits, momentum as float bits, 0}; total_blocks = sum of ceil(C / 256). */
+ * block), eps as float bits, momentum as float bits, pointer to the layer's int64 num_batches_tracked | 0 (incremented by
+ * one: nn.BatchNorm2d's counter, no launch of its own)}; total_blocks = sum of ceil(C / 256). */
 int frx_bn_finalize_batched(int device, frx_stream_t stream, int n, const int64_t* table_dev, int total_blocks);
 /* backward twin: totals (sum dz, sum dz*xhat) -> dgamma +=, dbeta +=, coef [3][C]; rows zeroed.  table_dev [n][16] int64 =
  * {totals, replicas, C, count, gamma, mean, invstd, dgamma | 0, dbeta | 0, coef, 0, 0, first block, 0, 0, 0} */
@@ -404,6 +411,16 @@ int frx_weight_prep(int device, frx_stream_t stream, int dtype, int Co, int RS, 
  * consecutive elements (no CRSK); mode 1: a block owns one 64(co) x 64(ci) tile of one tap (Co, Ci multiples of 64) */
 int frx_weight_prep_batched(int device, frx_stream_t stream, int dtype, int n, const int64_t* table_dev,
                             const float* master, int total_blocks);
+/* the optimiser step (model_utils.py:186, optim.SGD :557) and the kernel-format copies of the updated weights in ONE
+ * launch: frx_sgd_step's arithmetic on p / g / buf, with the blocks laid out by frx_weight_prep_batched's table -- a mode-1
+ * block updates its 64 x 64 tile of the fp32 master and writes the KRSC / CRSK copies from the values it holds -- plus
+ * mode 2 rows {offset (floats), length (multiple of 4), 0, 0, 0, 0, first block, 2} for the ranges that have no copy
+ * (BatchNorm affine, fc bias, margin head): a block updates 1024 consecutive elements.  The rows must cover every
+ * parameter exactly once.  zero_grads != 0: g is zeroed as it is consumed (optimizer.zero_grad() of the NEXT step,
+ * model_utils.py:184, folded in). */
+int frx_sgd_step_prep(int device, frx_stream_t stream, int dtype, int n, const int64_t* table_dev, int total_blocks,
+                      float* p, float* g, float* buf, const float* lr_dev, float lr, float momentum, float weight_decay,
+                      float grad_scale, int zero_grads);
 int frx_input_prep(int device, frx_stream_t stream, int dtype, int N, int H, int W, const void* images,
                    int is_u8_nhwc, void* out, int64_t out_elems);
 int frx_cast(int device, frx_stream_t stream, int dtype, int to_f32, int64_t n, const void* x, void* y);

@@ -41,16 +41,16 @@ for _ in range(REP):
     acc = ts if acc is None else [min(a, b) for a, b in zip(acc, ts)]
 rec = ops.PROFILER; ops.PROFILER = None
 tot = {}
-print(f"{'op':11s} {'kernel':24s} {'Ci':>5s} {'Co':>5s} k s {'Hi':>3s} {'us':>8s} {'TF/s':>7s} {'GB/s':>7s}")
+print(f"{'op':13s} {'Ci':>5s} {'Co':>5s} k s {'Hi':>3s} {'us':>8s} {'TF/s':>7s} {'GB/s':>7s}  kernel class")
 assert len(descs) == len(rec), (len(descs), len(rec))
 for nd, (label, flops, _, _, nb), us in zip(descs, rec, acc):
     if nd is None:
-        print(f"{'wgrad_group':11s} {label:24s} {'':5s} {'':5s}     {'':3s} {us:8.1f} {flops/us/1e6:7.1f} {nb/us/1e3:7.0f}")
+        print(f"{'wgrad_group':13s} {'':5s} {'':5s}     {'':3s} {us:8.1f} {flops/us/1e6:7.1f} {nb/us/1e3:7.0f}  {label}")
         tot['wgrad_group'] = tot.get('wgrad_group', 0) + us
         continue
     name, d = nd
     M_out = d.N * d.Ho * d.Wo; M_in = d.N * d.Hi * d.Wi
     byt = nb or 2 * (M_in * (4 if d.stem else d.Ci) + M_out * d.Co + d.Co * d.R * d.S * d.Ci)
-    print(f"{name:11s} {label:24s} {d.Ci:5d} {d.Co:5d} {d.R} {d.stride} {d.Hi:3d} {us:8.1f} {flops/us/1e6:7.1f} {byt/us/1e3:7.0f}")
+    print(f"{name:13s} {d.Ci:5d} {d.Co:5d} {d.R} {d.stride} {d.Hi:3d} {us:8.1f} {flops/us/1e6:7.1f} {byt/us/1e3:7.0f}  {label}")
     tot[name] = tot.get(name, 0) + us
 print({k: round(v / 1e3, 3) for k, v in tot.items()}, "ms")

@@ -3,9 +3,18 @@ Corrections (MI355X_MICROARCH.md, HBM): counters are in KiB; on gfx950 FETCH_SIZ
 requests at 64 bytes, so wide coalesced reads are doubled; WRITE_SIZE is exact for 16-byte stores."""
 import csv, glob, json, re, sys, collections
 root = sys.argv[1]
+MODE = {0: "fwd", 1: "dgrad", 2: "stem", 3: "fwd3x3patch", 4: "dgrad3x3patch"}
+PRO = {0: "none", 1: "bn_relu", 2: "bn_bwd"}
+EPI = {0: "plain", 1: "stats", 2: "bnbwd_stats", 3: "fc", 4: "bnbwd_stats_maskout"}
 def label(name):
-    m = re.search(r"k_igemmI(DF16b|f)Li(\d+)ELi(\d+)E", name)
-    if m: return f"k_igemm<{'bf16' if m.group(1)=='DF16b' else 'f32'},{m.group(2)},{m.group(3)}>"
+    # k_igemm<T, BM, BN, WM, WN, MODE, PRO, EPI, ADD, KC, PD, NS, PERSIST, SPEC>: the class label of frx/ops.py: igemm_class
+    m = re.search(r"k_igemmI(DF16b|f)((?:L[ib]\d+E)+)", name)
+    if m:
+        v = [int(x) for x in re.findall(r"L[ib](\d+)E", m.group(2))]
+        bm, bn, wm, wn, mode, pro, epi, add, kc, pd, ns, persist, spec = v[:13]
+        stage = "patch" if mode in (3, 4) else (f"dma{ns}" if ns else "ring")
+        return (f"k_igemm<{'bf16' if m.group(1)=='DF16b' else 'f32'},{bm}x{bn}x{wm * wn}w,kc{kc},{MODE[mode]},pro={PRO[pro]},epi={EPI[epi]}"
+                f"{'+add' if add else ''},{stage}{',persist' if persist else ''}{',stagewaves' if spec else ''}>")
     m = re.search(r"k_wgradI(DF16b|f)Li(\d+)E", name)
     if m: return f"k_wgrad<{'bf16' if m.group(1)=='DF16b' else 'f32'},{m.group(2)}>"
     return re.sub(r"\(.*", "", name)[:60]

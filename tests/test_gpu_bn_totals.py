@@ -94,6 +94,19 @@ def test_backward_with_totals_equals_the_deterministic_backward_of_the_same_forw
     g_tot = net.grads.clone()
     coefs_tot = [[c.clone() if c is not None else None for c in b.coefs] for b in net.blocks]
     assert float(net.bn_tot_b.abs().max()) == 0.0 and float(net.bn_tot_f.abs().max()) == 0.0
+    #  a check of the DEFAULT backward that compares no two runs: dbeta = sum dz, dgamma = sum dz * xhat of every
+    # bn3 and every projection BatchNorm -- the layers whose dz outlives the step (the block's masked output gradient) --
+    # against torch reductions of the engine's OWN dz / y buffers.  A stale or double-counted total, a totals row that was
+    # not zeroed, or a missed fork / join of the projection branch shows up here as O(1), rounding as 1e-5.
+    for b in net.blocks:
+        for c in (b.conv3, b.down):
+            if c is None:
+                continue
+            dz, yy = b.dz3.float().reshape(-1, c.Co), c.y.float().reshape(-1, c.Co)
+            xhat = (yy - net._bn(net.bn_mean, c)) * net._bn(net.bn_invstd, c)
+            for got, terms in ((net.beta(c, g_tot), dz), (net.gamma(c, g_tot), dz * xhat)):
+                tol = 2e-4 * terms.abs().sum(0) + 1e-7
+                assert ((got - terms.sum(0)).abs() <= tol).all(), (c.name, float(((got - terms.sum(0)).abs() / tol).max()))
     net.fused_bn = False
     try:
         net.zero_grad(); net.backward(df)
@@ -116,6 +129,36 @@ def test_backward_with_totals_equals_the_deterministic_backward_of_the_same_forw
             if cd is not None:
                 assert _rel(ct, cd) < 2e-2
     print(f"batch {n}: worst relative dW difference between the two backward forms {worst:.3e}")
+
+
+def test_projection_branch_on_a_side_stream_equals_the_in_line_order(monkeypatch):
+    """ FRX_BRANCH_STREAM = 1 (default: the projection branch of a layer's first block forks onto a side stream)
+    against = 0 (in line): same init, same batch, one forward + backward each.  The two orders do the same arithmetic; they
+    differ by the arrival order of float atomics and the bf16 flips that follow (measured 1e-3 .. 2e-2 in dW) -- a missed
+    join would leave a projection's gradients stale or half-written (O(1))."""
+    from frx import engine as E, ops
+    n, c = 16, 1000
+    engs = []
+    for v in ("1", "0"):
+        monkeypatch.setenv("FRX_BRANCH_STREAM", v)
+        engs.append(E.FaceEngine("arcface", c, n, dtype=ops.BF16, device=DEV, seed=0))
+    a, b = engs
+    assert a.net.branch_stream is not None and b.net.branch_stream is None and a.net.fused_bn and b.net.fused_bn
+    g = torch.Generator().manual_seed(11)
+    x = (torch.rand(n, 3, 112, 112, generator=g) * 2 - 1).to(DEV)
+    y = torch.randint(0, c, (n,), generator=g).to(DEV)
+    for e in (a, b):
+        e.net.training = True
+        e.net.zero_grad()
+        e.forward_loss(x, y)
+        e.backward(y)
+    torch.cuda.synchronize()
+    for ca, cb in zip(a.net.convs, b.net.convs):
+        r = _rel(a.net.w_grad(ca), b.net.w_grad(cb))
+        assert r < 5e-2, (ca.name, r)
+    for ba, bb in zip(a.net.blocks, b.net.blocks):
+        if ba.down is not None:
+            assert _rel(ba.down.y, bb.down.y) < 2e-2 and _rel(ba.out, bb.out) < 2e-2, ba.down.name
 
 
 def test_step_driver_with_totals_trains():

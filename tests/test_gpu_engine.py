@@ -221,6 +221,43 @@ def test_state_dict_round_trip_and_graph_capture(monkeypatch):
         assert abs(a - b) < 2e-2 * abs(b), (losses, eager)
 
 
+@pytest.mark.parametrize("dt", ["f32", "bf16"])
+def test_fused_update_equals_sgd_then_weight_prep(dt):
+    """frx_sgd_step_prep (one launch: SGD on the flat buffers + KRSC / CRSK kernel copies + zeroed gradients) against the
+    two launches it replaces, frx_sgd_step + frx_weight_prep_batched, on the same state: bit for bit on parameters,
+    momentum and every kernel-format weight; the gradient buffer is zero afterwards (model_utils.py:184-187)."""
+    from frx import engine as E, ops
+    eng = E.FaceEngine("arcface", 200, 4, dtype=ops.F32 if dt == "f32" else ops.BF16, device=DEV, seed=3)
+    net = eng.net
+    g = torch.Generator(device="cpu").manual_seed(1)
+    net.grads.copy_(torch.randn(net.n_params, generator=g) * 1e-2)
+    net.mom.copy_(torch.randn(net.n_params, generator=g) * 1e-2)
+    m = net.w_master(net.stem)
+    pad = torch.zeros_like(m, dtype=torch.bool); pad[:, :, 7, :] = True; pad[..., 3] = True
+    net.w_grad(net.stem)[pad] = 0; net.w_grad(net.stem, net.mom)[pad] = 0      # (padding slots carry exact zeros: engine invariant)
+    p0, g0, m0 = net.params.clone(), net.grads.clone(), net.mom.clone()
+    net.lr_dev.fill_(0.05)
+    net.sgd_step(None, 0.9, 5e-4, grad_scale=0.5)
+    assert float(net.grads.abs().max()) == 0.0
+    got = dict(p=net.params.clone(), m=net.mom.clone(), wk=[c.wk.clone() for c in net.convs],
+               wt=[c.wt.clone() for c in net.convs if c.wt is not None], fk=net.fc_wk.clone(), ft=net.fc_wt.clone())
+    net.params.copy_(p0); net.grads.copy_(g0); net.mom.copy_(m0)
+    ops.sgd_step(net.params, net.grads, net.mom, 0.0, 0.9, 5e-4, grad_scale=0.5, lr_dev=net.lr_dev)
+    net.sync_weights(pad=False)
+    assert torch.equal(net.grads, g0)                       # the plain kernel leaves the gradients alone
+    assert torch.equal(got["p"], net.params) and torch.equal(got["m"], net.mom)
+    assert not torch.equal(net.params, p0)
+    for a, c in zip(got["wk"], net.convs):
+        assert torch.equal(a, c.wk), c.name
+    for a, c in zip(got["wt"], [c for c in net.convs if c.wt is not None]):
+        assert torch.equal(a, c.wt), c.name
+    assert torch.equal(got["fk"], net.fc_wk) and torch.equal(got["ft"], net.fc_wt)
+    # zero_grads=False (FusedSGD.step keeps torch's semantics: .grad survives the step)
+    net.grads.copy_(g0)
+    net.sgd_step(0.01, zero_grads=False)
+    assert torch.equal(net.grads, g0)
+
+
 def test_sgd_kernel_matches_torch_sgd():
     """Fused flat SGD (momentum 0.9, wd 5e-4, model_utils.py:557) vs the oracle restatement, 3 steps,
     odd length (tail path) and lr read from the device scalar."""
