@@ -88,22 +88,31 @@ def kernel_pass(eng, images, labels, steps=3):
     # (a launch is timed ALONE: the side stream that runs the projection branches next to the conv chain in the timed step
     # would charge each launch for its neighbour here -- in line for this pass)
     side, eng.net.branch_stream = eng.net.branch_stream, None
-    eng.train_step(images, labels)
+    net = eng.net
+
+    def eager_step(check=False):
+        # the step's stages, eagerly (the fused update zeroes the gradients it consumes: they are inspected before it)
+        eng.pre_step()
+        eng.stage_forward(images, labels)
+        eng.stage_upper(labels)
+        eng.stage_lower()
+        if check:
+            # work integrity: the step must have produced a weight gradient for EVERY conv layer (a kernel that silently
+            # does nothing makes the benchmark faster, not slower -- this is what would show it)
+            dead = [c.name for c in net.convs if float(net.w_grad(c).abs().max()) == 0.0]
+            if dead:
+                raise SystemExit(f"bench: integrity check failed: zero weight gradient in {len(dead)} conv layers, e.g. {dead[:4]}")
+        eng.stage_update()
+    eager_step()
     torch.cuda.synchronize()
     per_step = []
-    for _ in range(steps):
+    for i in range(steps):
         ops.PROFILER = []
-        eng.train_step(images, labels)
+        eager_step(check=(i == steps - 1))
         torch.cuda.synchronize()
         per_step.append([(label, flops, e0.elapsed_time(e1) * 1e-3, nbytes) for label, flops, e0, e1, nbytes in ops.PROFILER])
     ops.PROFILER = None
     eng.net.branch_stream = side
-    # work integrity: the step just run must have produced a weight gradient for EVERY conv layer (a kernel that
-    # silently does nothing makes the benchmark faster, not slower -- this is what would show it)
-    net = eng.net
-    dead = [c.name for c in net.convs if float(net.w_grad(c).abs().max()) == 0.0]
-    if dead:
-        raise SystemExit(f"bench: integrity check failed: zero weight gradient in {len(dead)} conv layers, e.g. {dead[:4]}")
     agg = {}
     for calls in zip(*per_step):
         label, flops, _, nbytes = calls[0]

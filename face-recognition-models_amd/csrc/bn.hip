@@ -211,7 +211,9 @@ __global__ __launch_bounds__(256) void k_merge_fwd(long rows, int C, const T* __
         unsigned bits = 0;
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-          o.set(j, fmaxf(fmaf(a[u].get(j), ks[j], kb[j]) + fmaf(b[u].get(j), ds[j], db[j]), 0.f));
+          // (fma for fma the expression of conv_kernels.h: merge_vec -- a consumer that evaluates the merge in its prologue
+          // (frx_conv_fwd_merge) stages exactly the value this pass writes)
+          o.set(j, fmaxf(fmaf(a[u].get(j), ks[j], fmaf(b[u].get(j), ds[j], kb[j] + db[j])), 0.f));
           bits |= (o.get(j) > 0.f ? 1u : 0u) << j;      // of the ROUNDED output: what `out > 0` would see
         }
         if (rr < rows) {
@@ -663,12 +665,8 @@ static inline int row_grid(long rows, int C, int V) {
 }
 
 // Row sweeps whose blocks first derive their constants from replicated totals run fewer, longer-lived blocks: the
-// derivation is paid per block (FRX_TOT_ROW_GRID: tuning aid, read per launch)
-static inline int tot_row_grid(int grid) {
-  int cap = 512;
-  if (const char* e = getenv("FRX_TOT_ROW_GRID")) cap = atoi(e) > 0 ? atoi(e) : cap;
-  return grid < cap ? grid : cap;
-}
+// derivation is paid per block
+static inline int tot_row_grid(int grid) { return grid < 512 ? grid : 512; }
 
 static inline int pool_grid(long work_items) {       // multiple of 8: the pool kernels split the index space per XCD
   long b = (work_items + 255) / 256;

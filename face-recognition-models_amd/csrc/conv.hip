@@ -21,7 +21,6 @@ static bool p3_geometry(int dtype, int R, int S, int stride, int pad, int Wx, in
 static void p3_tile(long M, int Ncol, int* bm, int* bn) {
   *bn = Ncol % 128 == 0 ? 128 : 64;
   *bm = (*bn == 128 && (long)cdiv(M, 128) * (Ncol / 128) < 192) ? 64 : 128;
-  if (const char* e = getenv("FRX_P3_BM")) { if (atoi(e) == 128) *bm = 128; }      // (tuning aid)
 }
 
 static thread_local int t_last_launch[12] = {0};
@@ -61,17 +60,16 @@ static int launch_igemm(hipStream_t st, ConvArgs a, int dtype) {
   a.nvb = (int)round_up(a.tilesM, 8) * a.tilesN;
   // Persistent blocks (conv_kernels.h: run_tile) when the launch has more tiles than fit on the chip at once and its
   // statistics (if any) go to replicated totals: `cap` resident blocks walk the tiles with a fixed stride.  cap / 8 is a
-  // multiple of tilesN (a block stays in one column of tiles).  FRX_IGEMM_PERSIST=0: off; =N: N blocks per CU.
+  // multiple of tilesN (a block stays in one column of tiles).
   int grid = a.nvb;
   {
-    int per_cu = c.waves == 8 ? 2 : 3;
-    if (const char* e = getenv("FRX_IGEMM_PERSIST")) per_cu = atoi(e);
+    const int per_cu = c.waves == 8 ? 2 : 3;
     const int cap = per_cu * 256;
     // (the instantiated persistent variants: forward only.  Measured per launch inside a training step, persistent vs one
     // tile per block: the prologue-fed pointwise forwards of layer1/2 gain 7-9 % (the 64->256 conv3: 42.1 -> 38.9 us),
     // the input gradients LOSE 8-15 % -- their epilogues are where the registers run out, and a tile loop without
     // cross-tile prefetch only adds live state there: profiles/r03_persist_layer_times.txt)
-    const bool tile_ok = c.kc == 64 && c.bm == 128 && !c.ns && a.mode == MODE_FWD;
+    const bool tile_ok = c.kc == 64 && c.bm == 128 && !c.ns && a.mode == MODE_FWD && !a.X2;      // (the merge prologue has no persistent instantiation: it spills there)
     if (per_cu > 0 && tile_ok && !a.stat_partial && a.nvb > cap && (cap / 8) % a.tilesN == 0) grid = cap;
   }
   int epi = EPI_PLAIN;
@@ -98,7 +96,7 @@ static int launch_igemm(hipStream_t st, ConvArgs a, int dtype) {
       a.nvb = (int)round_up(a.tilesM, 8) * a.tilesN;
       return launch_igemm_p3(st, a, epi, bm3, bn3);
     }
-    FRX_CHECK_ARG(!(a.dy_out && a.mode == MODE_FWD),
+    FRX_CHECK_ARG(!(a.dy_out && a.mode == MODE_FWD && !a.X2),
                   "conv_fwd_keep: x_norm_out needs the patch-mode launch (partial-statistics rows only where frx_conv_tile's row tile is "
                   "frx_conv_patch_mode's)");
     FRX_CHECK_ARG(!(a.dy_out && (a.R != 1 || a.S != 1)),
@@ -110,6 +108,10 @@ static int launch_igemm(hipStream_t st, ConvArgs a, int dtype) {
     return a.X2 ? launch_igemm_dgrad_bn(st, a, dtype, c, grid, epi, a.addend != nullptr)
                 : launch_igemm_dgrad_plain(st, a, dtype, c, grid, epi, a.addend != nullptr);
   FRX_CHECK_ARG(a.addend == nullptr, "igemm fwd: addend is a dgrad feature");
+  if (a.X2) {      // the merge prologue (frx_conv_fwd_merge)
+    FRX_CHECK_ARG(pointwise, "conv_fwd_merge: a 1x1 / stride 1 convolution");
+    return launch_igemm_fwd(st, a, dtype, c, grid, 3, epi);
+  }
   return launch_igemm_fwd(st, a, dtype, c, grid, (a.in_scale || a.in_tot.tot) ? 1 : 0, epi);
 }
 
@@ -149,7 +151,7 @@ extern "C" int frx_conv_tile(const frx_conv_desc* d, int dgrad, int* bm, int* bn
   const bool pw = d->R == 1 && d->S == 1 && d->stride == 1;
   TileCfg c;
   if (dgrad) {
-    const bool s2c = d->stride == 2 && (d->R > 1 || d->S > 1) && !getenv("FRX_DGRAD_NO_S2C");
+    const bool s2c = d->stride == 2 && (d->R > 1 || d->S > 1);
     c = pick_tile((long)d->N * d->Hi * d->Wi, d->Ci, (long)d->R * d->S * d->Co, pw, !s2c);
     if (d->Ci % c.bn != 0) c.bn = 64;
   } else {
@@ -251,6 +253,38 @@ extern "C" int frx_conv_fwd_keep(int device, frx_stream_t stream, const frx_conv
                        x_norm_out);
 }
 
+// The residual merge of the block BEFORE as the prologue of a 1x1 convolution (replaces that block's frx_block_merge_fwd*
+// launch: torchvision Bottleneck.forward's `out += identity; out = relu(out)` feeding the next Bottleneck's conv1,
+// backbones.py:16-18): x = relu(bn3(y3) + idn') is evaluated while the tiles are staged, stored once (block_out, mask) by the
+// first column of tiles, and never read back by this launch.
+extern "C" int frx_conv_fwd_merge(int device, frx_stream_t stream, const frx_conv_desc* d, const void* y3, const void* idn,
+                                  const void* w, const float* s3, const float* b3, const float* sd, const float* bd,
+                                  const frx_bn_tot* bn3, const frx_bn_tot* bnd, void* block_out, uint8_t* mask, void* y,
+                                  float* stat_partial, float* stat_totals, int stat_replicas) {
+  if (int rc = check_conv(d)) return rc;
+  FRX_CHECK_ARG(!d->stem && d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0, "conv_fwd_merge: a 1x1 / stride 1 convolution");
+  FRX_CHECK_ARG(y3 && idn && w && y && block_out, "conv_fwd_merge: NULL pointer");
+  FRX_CHECK_ARG((s3 != nullptr) != (bn3 != nullptr) && (s3 == nullptr) == (b3 == nullptr), "conv_fwd_merge: bn3 as arrays (s3, b3) OR as totals");
+  FRX_CHECK_ARG((sd == nullptr) == (bd == nullptr) && !(sd && bn3) && !(bnd && s3), "conv_fwd_merge: the projection's constants in the same form as bn3's");
+  FRX_CHECK_ARG(!(stat_partial && stat_totals), "conv_fwd_merge: statistics as partial rows OR as totals");
+  FRX_CHECK_ARG(!stat_totals || frx_pow2(stat_replicas), "conv_fwd_merge: stat_replicas must be a power of two");
+  FRX_CHECK_ARG(d->Ci <= 2048, "conv_fwd_merge: up to 2048 input channels (got %d)", d->Ci);
+  for (const frx_bn_tot* t : {bn3, bnd})
+    if (t) FRX_CHECK_ARG(t->totals && t->gamma && t->beta && frx_pow2(t->replicas) && t->count > 0.f,
+                         "conv_fwd_merge: a BatchNorm as totals needs totals / gamma / beta, a power-of-two replica count and count > 0");
+  FRX_ENTER(device);
+  ConvArgs a{};
+  a.X = y3; a.X2 = idn; a.W = w; a.Y = y;
+  a.in_scale = s3; a.in_shift = b3; a.id_scale = sd; a.id_shift = bd; a.in_relu = 1;
+  a.in_tot = bn_tot_arg(bn3); a.id_tot = bn_tot_arg(bnd);
+  a.dy_out = block_out; a.mask_out = mask;
+  a.stat_partial = stat_partial; a.stat_tot = stat_totals; a.stat_R = stat_replicas;
+  a.N = d->N; a.Ho = d->Ho; a.Wo = d->Wo; a.Ncol = d->Co; a.R = 1; a.S = 1; a.stride = 1; a.pad = 0;
+  a.M = d->N * d->Ho * d->Wo;
+  a.mode = MODE_FWD; a.Hx = d->Hi; a.Wx = d->Wi; a.Kc = d->Ci;
+  return launch_igemm((hipStream_t)stream, a, d->dtype);
+}
+
 extern "C" int frx_conv_fwd_tot(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x, const void* w,
                                 const frx_bn_tot* in_bn, int in_relu, void* y, float* stat_totals, int stat_replicas) {
   return conv_fwd_impl(device, stream, d, x, w, nullptr, nullptr, in_relu, nullptr, y, 0, nullptr, in_bn, stat_totals, stat_replicas);
@@ -268,7 +302,7 @@ static int dgrad_impl(int device, frx_stream_t stream, const frx_conv_desc* d, c
   a.stride = d->stride; a.pad = d->pad;
   a.M = d->N * d->Hi * d->Wi;
   a.mode = MODE_DGRAD;
-  a.s2c = (d->stride == 2 && (d->R > 1 || d->S > 1) && !getenv("FRX_DGRAD_NO_S2C")) ? 1 : 0;
+  a.s2c = (d->stride == 2 && (d->R > 1 || d->S > 1)) ? 1 : 0;
   if (f) {
     if (f->pro_y) {
       FRX_CHECK_ARG((f->pro_coef != nullptr) != (f->pro_tot != nullptr), "conv_dgrad_bn: pro_y needs pro_coef or pro_tot (one of them)");
@@ -323,7 +357,7 @@ extern "C" int frx_conv_dgrad_bn(int device, frx_stream_t stream, const frx_conv
 extern "C" int frx_conv_dgrad_stat_rows(const frx_conv_desc* d) {
   if (check_conv(d) != FRX_OK) return -1;
   const long M = (long)d->N * d->Hi * d->Wi;
-  const bool s2c = d->stride == 2 && (d->R > 1 || d->S > 1) && !getenv("FRX_DGRAD_NO_S2C");
+  const bool s2c = d->stride == 2 && (d->R > 1 || d->S > 1);
   const int bm = pick_tile(M, d->Ci, (long)d->R * d->S * d->Co, d->R == 1 && d->S == 1 && d->stride == 1, !s2c).bm;
   if (s2c) {                                             // parity-class tiles (launch_igemm)
     int t = 0;
@@ -396,13 +430,12 @@ static int wgrad_impl(int device, frx_stream_t stream, const frx_conv_desc* d, c
 // ---- grouped launch: table = [njobs] WgradArgs, 8 draw counters (one per XCD, zero between launches), then [nitems] WgradItem
 static inline size_t group_counters_offset(int njobs) { return round_up((long)njobs * (long)sizeof(WgradArgs), 256); }
 static inline size_t group_items_offset(int njobs) { return group_counters_offset(njobs) + 256; }
-static int group_chunks_per_item() { const char* e = getenv("FRX_WGRAD_GROUP_CHUNKS"); return e ? atoi(e) : 64; }
+static int group_chunks_per_item() { return 64; }      // measured sweep (scripts/group_sweep.sh, round 2)
 
 static int group_build(const frx_wgrad_job* jobs, int njobs, std::vector<WgradArgs>* layers, std::vector<WgradItem>* items) {
   FRX_CHECK_ARG(jobs && njobs > 0, "wgrad_group: no jobs");
   const int target = group_chunks_per_item();
-  const char* es = getenv("FRX_WGRAD_SCATTER_CHUNKS");
-  const int scatter_chunks = es ? atoi(es) : 128;
+  const int scatter_chunks = 128;
   // (layer, split) groups stream the same pixel range: keep each on ONE XCD (block b runs on XCD b % 8, item p is
   // taken by block p % grid), so its tiles share that L2.  Groups go round-robin to the least loaded XCD list.
   std::vector<std::vector<WgradItem>> xl(8);

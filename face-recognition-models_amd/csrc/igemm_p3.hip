@@ -24,8 +24,7 @@ namespace frx {
     else FRX_P3S(128, 128, 2, 2, MODE_, PRO_, EPI_);                                        \
   } while (0)
 int launch_igemm_p3(hipStream_t st, const ConvArgs& a, int epi, int bm, int bn) {
-  const char* e = getenv("FRX_P3_SPEC");
-  const bool spec = !(e && atoi(e) == 0) && bn == 128 && (long)a.tilesM * a.tilesN <= 256;
+  const bool spec = bn == 128 && (long)a.tilesM * a.tilesN <= 256;
   if (spec && a.mode == MODE_FWD && epi == EPI_STATS) FRX_P3S_T(MODE_FWD3, 1, EPI_STATS);
   else if (spec && a.mode == MODE_FWD && epi == EPI_PLAIN) FRX_P3S_T(MODE_FWD3, 1, EPI_PLAIN);
   else if (spec && a.mode == MODE_DGRAD && epi == EPI_BNBWD && a.X2) FRX_P3S_T(MODE_DGRAD3, 2, EPI_BNBWD);

@@ -23,9 +23,7 @@ int launch_wgrad(hipStream_t st, const WgradArgs& a, int dtype, int bt, int wmod
 // fewer when the list is short
 int launch_wgrad_grouped(hipStream_t st, int dtype, const WgradArgs* layers, const WgradItem* items, int nitems, bool small_tiles,
                          int* draw_counters) {
-  if (getenv("FRX_WGRAD_STATIC")) draw_counters = nullptr;      // tuning aid: the fixed-stride item order
-  const char* e = getenv(small_tiles ? "FRX_WGRAD_GROUP_BLOCKS_SMALL" : "FRX_WGRAD_GROUP_BLOCKS");
-  int grid = e ? atoi(e) : (small_tiles ? 1024 : 512);
+  int grid = small_tiles ? 1024 : 512;
   if (grid > nitems) grid = nitems;
   grid = grid / 8 * 8;
   if (grid < 8) grid = 8;

@@ -69,8 +69,6 @@ class DataParallelStep:
                             and getattr(engine, "shard", None) is None)
         if hasattr(engine, "set_head_bucket"):       # (sticky engine state: a single-GPU stepper on the same engine resets it;
             engine.set_head_bucket(self.head_bucket)  # both flags are part of the engine's graph_key())
-        # one graph for the whole step: the upper weight-gradient list may still run (side stream, FRX_WGRAD_STREAM=1) while
-        # the lower backward proceeds; with buckets its gradients must be final where the "upper" segment ends
         net = getattr(engine, "net", None)
         if net is not None and hasattr(net, "join_after_upper"):
             net.join_after_upper = self.multi

@@ -206,11 +206,7 @@ class ResNet50Engine:
         self.g_pool = torch.zeros_like(self.pool_out)        # gradient w.r.t. the max-pool output
         self.dy_stem = torch.zeros_like(self.stem.y)
         self.grouped_wgrad = os.environ.get("FRX_WGRAD_GROUPED", "1") != "0"
-        # FRX_WGRAD_STREAM=1: the grouped weight-gradient lists run on a side stream next to the input gradients of the layers
-        # below them (a fork / join inside the captured step)
-        self.wgrad_stream = (torch.cuda.Stream(device=dev) if (dev.type == "cuda" and self.grouped_wgrad
-                                                              and os.environ.get("FRX_WGRAD_STREAM", "0") == "1") else None)
-        self.join_after_upper = True
+        self.join_after_upper = True       # (kept in graph_key(): a data-parallel plan ends a segment after the upper list)
         # the projection branch of a layer's first block (conv + BN forward; BN-backward reduce + input / weight gradient
         # backward) is independent of the conv1-conv2-conv3 chain until the merge / until conv1's input gradient: it runs on a
         # side stream next to the chain (fork / join inside the captured step).  Replicated-totals mode only (the partial-rows
@@ -223,8 +219,9 @@ class ResNet50Engine:
         self.fused_bn = (dtype == BF16 and self.grouped_wgrad and os.environ.get("FRX_BN_DETERMINISTIC", "0") != "1")
         if self.fused_bn:
             self._plan_bn_totals()
-        self.fused_stem_bwd = os.environ.get("FRX_FUSED_STEM_BWD", "1") != "0"
-        self.mask_bits = os.environ.get("FRX_MASK_BITS", "1") != "0"
+        self.merge_fuse = os.environ.get("FRX_MERGE_FUSE", "all")
+        self.fused_stem_bwd = True         # (False: max-pool backward + stand-alone BN backward, the form the fused stem kernels are tested against)
+        self.mask_bits = True              # (False: the backward re-reads the block output instead of its 1-bit mask)
         self._wg_groups = None                               # planned at the end of __init__ (needs every buffer)
         self.dfeat_t = torch.zeros(N, FEATURE_DIM, dtype=self.tdt, device=dev)
         self.lr_dev = torch.zeros(1, device=dev)
@@ -250,7 +247,7 @@ class ResNet50Engine:
             b.dy2 = torch.zeros_like(b.conv2.y)
             c2 = b.conv2
             pm = ops.conv_patch_mode(c2.desc, False) if (c2.k == 3 and c2.stride == 1) else 0
-            if pm and pm == ops._igemm_tile(c2.desc)[0] and os.environ.get("FRX_KEEP_XNORM", "1") != "0":
+            if pm and pm == ops._igemm_tile(c2.desc)[0]:
                 c2.x_norm = torch.zeros_like(b.conv1.y)      # (the grouped lists: -78 us per step)
             b.dyc = {c.name: torch.zeros_like(c.y) for c in (b.conv1, b.conv3, b.down) if c is not None and self._keeps_dy(c)}
         self._train_ready = True
@@ -268,7 +265,7 @@ class ResNet50Engine:
             # The layers whose backward sums come from a stand-alone reduce launch (512 blocks that finish together: the
             # projections' BatchNorms, the last bn3) keep 8.
             tiles = (c.y.numel() // c.Co + 127) // 128
-            big = int(os.environ.get("FRX_BN_R", "8"))          # (tuning aid)
+            big = 8                                            # (4 measures the same, 2 and 16 worse: DESIGN.md 8.0)
             c.R = 2 * big if c.stem else (big if (tiles >= 256 or c.name in fed_by_reduce) else (2 if tiles >= 64 else 1))
         tot = sum(c.R * 2 * c.Co for c in self.convs)
         self.bn_tot_f = torch.zeros(tot, device=dev)
@@ -440,6 +437,16 @@ class ResNet50Engine:
             ops.conv_fwd(c.desc, x, c.wk, c.y, **kw)
         return c.y
 
+    def _merge_fused(self, b):
+        """whether block b's residual merge runs as the prologue of the next block's conv1 (replicated-totals training
+        forward; FRX_MERGE_FUSE: "0" never, "all" wherever the next block has no projection, or the layers it pays in, e.g.
+        "12" -- measured per layer inside a training step)"""
+        sel = self.merge_fuse
+        if sel == "0":
+            return False
+        layer = PLANES.index(b.conv1.Co) + 1
+        return sel == "all" or str(layer) in sel
+
     def _prepare_eval_affine(self):
         for c in self.convs:
             ops.bn_eval_affine(self.gamma(c), self.beta(c), self._bn(self.running_mean, c),
@@ -481,16 +488,37 @@ class ResNet50Engine:
                               self.pool_out, self.pool_arg)
         x = self.pool_out
         side = self.branch_stream if fused else None
-        for b in self.blocks:
+        pending = None                  # (block, its input): a merge deferred into the next block's conv1 (frx_conv_fwd_merge)
+        for bi, b in enumerate(self.blocks):
             if side is not None and b.down is not None:      # projection next to the chain
                 side.wait_stream(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(side):
                     self._conv_bn(b.down, x, None)
-            self._conv_bn(b.conv1, x, None)
+            if pending is not None:
+                # the block before's out = relu(bn3(y3) + identity) is evaluated in this conv1's prologue and stored once on the
+                # way (its merge pass: a read of the block output and a launch less per block)
+                pb, px = pending
+                pending = None
+                if pb.down is not None and side is not None:
+                    torch.cuda.current_stream(self.device).wait_stream(side)
+                c1 = b.conv1
+                ops.conv_fwd_merge(c1.desc, pb.conv3.y, pb.down.y if pb.down is not None else px, c1.wk, c1.y, pb.out,
+                                   mask=pb.mask if self.mask_bits else None, bn3=pb.conv3.tot_f,
+                                   bnd=pb.down.tot_f if pb.down is not None else None,
+                                   stat_totals=c1.tot_f_buf, stat_replicas=c1.R)
+            else:
+                self._conv_bn(b.conv1, x, None)
             self._conv_bn(b.conv2, b.conv1.y, b.conv1)
             self._conv_bn(b.conv3, b.conv2.y, b.conv2)
             rows = b.out.numel() // b.conv3.Co
             if fused:
+                nxt = self.blocks[bi + 1] if bi + 1 < len(self.blocks) else None
+                if nxt is not None and nxt.down is None and self._merge_fused(b):
+                    if b.down is not None and side is None:
+                        self._conv_bn(b.down, x, None)
+                    pending = (b, x)          # nothing reads b.out before the next conv1 has stored it
+                    x = b.out
+                    continue
                 if b.down is not None:
                     if side is not None:
                         torch.cuda.current_stream(self.device).wait_stream(side)
@@ -620,25 +648,16 @@ class ResNet50Engine:
         self._backward_blocks(len(self.blocks) - 1, self.SPLIT_BLOCK)
         self._close_bn_bwd(0)
         self._run_wgrad_group(0)
-        if self.join_after_upper:          # (the upper gradient ranges are final when this returns: what a bucket's all-reduce needs)
-            self.join_wgrad()
 
     def backward_lower(self):
-        if self.wgrad_stream is not None:
-            # layer2's list starts as soon as layer2's input gradients are done and runs next to layer1's
-            self._backward_blocks(self.SPLIT_BLOCK - 1, LAYERS[0])
-            self._close_bn_bwd(1)
-            self._run_wgrad_group(1)
-            self._backward_blocks(LAYERS[0] - 1, 0)
-            self._backward_stem()
-        else:
-            self._backward_blocks(self.SPLIT_BLOCK - 1, 0)
-            self._backward_stem()
-            self._close_bn_bwd(1)
-            self._run_wgrad_group(1)
+        # (the weight-gradient lists of layer2 and of layer1 + stem run after ALL their input gradients: overlapping a list
+        # with the input gradients below it on a side stream measured 0.03 ms slower, profiles/r03_wgrad_side_stream.txt)
+        self._backward_blocks(self.SPLIT_BLOCK - 1, 0)
+        self._backward_stem()
+        self._close_bn_bwd(1)
+        self._run_wgrad_group(1)
         self._close_bn_bwd(2)
         self._run_wgrad_group(2)
-        self.join_wgrad()
 
     def _close_bn_bwd(self, which):
         """replicated totals of one group of BatchNorm layers -> dgamma / dbeta (+=) and the coefficient arrays the grouped
@@ -828,20 +847,7 @@ class ResNet50Engine:
             return
         if self._wg_groups is None:
             self._plan_wgrad_groups()
-        if self.wgrad_stream is None:
-            ops.wgrad_group_run(self._wg_groups[which])
-            return
-        # fork: the list runs on the side stream, next to the input gradients of the layers below (it reads per-block
-        # buffers and writes its own gradient ranges only); join_wgrad() brings the streams back together
-        self.wgrad_stream.wait_stream(torch.cuda.current_stream(self.device))
-        with torch.cuda.stream(self.wgrad_stream):
-            ops.wgrad_group_run(self._wg_groups[which])
-        self._wgrad_forked = True
-
-    def join_wgrad(self):
-        if getattr(self, "_wgrad_forked", False):
-            torch.cuda.current_stream(self.device).wait_stream(self.wgrad_stream)
-            self._wgrad_forked = False
+        ops.wgrad_group_run(self._wg_groups[which])
 
     # ------------------------------------------------------------------ optimiser
     def zero_grad(self):
@@ -861,6 +867,13 @@ class ResNet50Engine:
         of the gradient buffer the next step accumulates into (model_utils.py:184-187)."""
         if getattr(self, "_prep_table", None) is None:
             self._build_prep_table()
+        if os.environ.get("FRX_AB_SGD", "1") == "0":       # (A/B aid of round 4: the three launches the fused one replaced)
+            ops.sgd_step(self.params, self.grads, self.mom, 0.0 if lr is None else lr, momentum, weight_decay, grad_scale,
+                         lr_dev=self.lr_dev if lr is None else None)
+            self.sync_weights(pad=False)
+            if zero_grads:
+                self.zero_grad()
+            return
         ops.sgd_step_prep(self.dtype, self._prep_table, self._sgd_blocks, self.params, self.grads, self.mom,
                           0.0 if lr is None else lr, momentum, weight_decay, grad_scale,
                           lr_dev=self.lr_dev if lr is None else None, zero_grads=zero_grads)
@@ -969,12 +982,6 @@ class FaceEngine:
         self.elastic_std = float(elastic_std)
         self.elastic_plus = bool(elastic_plus) and self.kind in ELASTIC_KINDS      # rank-matched margins (criterion.py:1006-1011)
         head_flags = HEAD_FLAG_DEFAULTS.get(self.kind, 0) if head_flags is None else head_flags
-        # bf16 speed mode: the head's three GEMMs on the bf16 matrix cores by operand splitting (hi + lo, three MFMA passes:
-        # logits within 1e-4 of the exact-fp32 GEMM, ~5x its rate); the fp32 parity mode keeps the exact fp32 MFMA chain
-        # (off by default: measured no faster than the exact kernel -- the head's GEMMs are bound by their tile staging,
-        # not by the matrix pipe: profiles/r03_head_gemm_kernels.txt; FRX_HEAD_GEMM=bf16x3 switches it on)
-        if dtype == BF16 and os.environ.get("FRX_HEAD_GEMM", "f32") == "bf16x3":
-            head_flags |= 16
         self.head = ops.HeadContext(self.kind, self.N_g, FEATURE_DIM, self.C, self.s, self.m, momentum, device=self.device,
                                     p=self.head_p, flags=head_flags, lambda_g=lambda_g,
                                     class_offset=self.c0 if shard is not None else None)

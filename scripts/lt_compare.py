@@ -6,8 +6,8 @@ def rows(f):
     out = []
     for l in open(f):
         p = l.split()
-        if len(p) >= 9 and p[0].startswith("conv"):
-            out.append((p[0].replace("conv_fwd_tot", "conv_fwd"), p[1], tuple(p[2:7]), float(p[7])))
+        if len(p) >= 10 and p[0].startswith("conv"):      # op Ci Co k s Hi us TF/s GB/s class
+            out.append((p[0].replace("conv_fwd_tot", "conv_fwd"), p[9], tuple(p[1:6]), float(p[6])))
     return out
 fs = sys.argv[1:]
 R = [rows(f) for f in fs]

@@ -230,32 +230,3 @@ def test_inputs_of_another_size_and_labels_out_of_range_are_caught():
         assert torch.isnan(out["loss"]).all()
         if kind == "vpl_arcface":                 # the class memory is only written for the valid labels
             assert torch.isfinite(e2.t).all() and (e2.t[:C * 512].view(C, 512)[[0, 3, 1]].abs().sum(1) > 0).all()
-
-
-def test_weight_gradient_lists_on_a_side_stream(monkeypatch):
-    """FRX_WGRAD_STREAM=1 (engine.py: the grouped weight-gradient lists fork onto a side stream inside the captured step and
-    join before the update): same gradients as the in-line order, eagerly and through graph replay.  fp32 engines: the two
-    orders differ by the order of the lists' fp32 atomics only."""
-    from frx import ddp, ops
-    N, C = 8, 64
-    monkeypatch.setenv("FRX_WGRAD_STREAM", "1")
-    a = _eng("arcface", N, C, ops.F32)
-    assert a.net.wgrad_stream is not None
-    monkeypatch.setenv("FRX_WGRAD_STREAM", "0")
-    b = _eng("arcface", N, C, ops.F32)
-    assert b.net.wgrad_stream is None
-    (x, y), = _batches(1, N, C, seed=4)
-    for e in (a, b):
-        e.net.training = True
-        e.net.zero_grad()
-        e.forward_loss(x, y)
-        e.backward(y)
-    torch.cuda.synchronize()
-    assert _rel(a.net.grads, b.net.grads) < 1e-5
-    st = ddp.DataParallelStep(a)
-    assert a.net.join_after_upper is False, "one graph for the whole step: the upper list may run under the lower backward"
-    for i, (x, y) in enumerate(_batches(3, N, C, seed=5)):
-        oa = st.step(x, y, 0.01)
-        ob = b.train_step(x, y, 0.01)
-        assert oa["loss"].item() == pytest.approx(ob["loss"].item(), rel=1e-4 if i < 2 else 2e-2)
-    assert st.graphed and torch.isfinite(a.net.params).all()
