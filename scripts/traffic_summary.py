@@ -4,7 +4,7 @@ requests at 64 bytes, so wide coalesced reads are doubled; WRITE_SIZE is exact f
 import csv, glob, json, re, sys, collections
 root = sys.argv[1]
 MODE = {0: "fwd", 1: "dgrad", 2: "stem", 3: "fwd3x3patch", 4: "dgrad3x3patch"}
-PRO = {0: "none", 1: "bn_relu", 2: "bn_bwd", 3: "merge"}
+PRO = {0: "none", 1: "bn_relu", 2: "bn_bwd"}
 EPI = {0: "plain", 1: "stats", 2: "bnbwd_stats", 3: "fc", 4: "bnbwd_stats_maskout"}
 def label(name):
     # k_igemm<T, BM, BN, WM, WN, MODE, PRO, EPI, ADD, KC, PD, NS, PERSIST, SPEC>: the class label of frx/ops.py: igemm_class
