@@ -396,8 +396,25 @@ static inline size_t group_counters_offset(int njobs) { return round_up((long)nj
 static inline size_t group_items_offset(int njobs) { return group_counters_offset(njobs) + 256; }
 static int group_chunks_per_item() { return 64; }      // measured sweep (scripts/group_sweep.sh, round 2)
 
-static int group_build(const frx_wgrad_job* jobs, int njobs, std::vector<WgradArgs>* layers, std::vector<WgradItem>* items) {
+// A job with `gram` / `xsum` set is a DECOMPOSED weight gradient (frx_wgrad_gram_finish): its main layer accumulates the plain
+// dz^T x into dw, and a second, internal layer -- the same x as BOTH operands, one Ci x Ci tile -- accumulates G = x^T x into
+// `gram` and the column sums of x into `xsum`.  The table therefore holds more layers than there are jobs: *nlayers.
+static int gram_args(const frx_wgrad_job& j, WgradArgs& ag, WgradGeom& gg) {
+  FRX_CHECK_ARG(j.gram && j.xsum, "wgrad_group: gram and xsum come together");
+  FRX_CHECK_ARG(!j.pro_y && !j.pro_coef, "wgrad_group: a decomposed job takes the plain dz (no pro_y / pro_coef)");
+  FRX_CHECK_ARG(j.d.R == 1 && j.d.S == 1 && j.d.stride == 1 && !j.d.stem, "wgrad_group: decomposed jobs are 1x1 / stride 1 convolutions");
+  FRX_CHECK_ARG(j.d.Ci <= 128, "wgrad_group: a decomposed job's x^T x must fit one tile (Ci <= 128, got %d)", j.d.Ci);
+  frx_conv_desc dg = j.d;
+  dg.Co = dg.Ci;
+  if (int rc = wgrad_args(&dg, j.x, j.in_scale, j.in_shift, j.in_relu, j.x, nullptr, nullptr, j.gram, ag, gg)) return rc;
+  ag.variant |= WGV_GRAM;
+  ag.xsum = j.xsum;
+  return FRX_OK;
+}
+
+static int group_build(const frx_wgrad_job* jobs, int njobs, std::vector<WgradArgs>* layers, std::vector<WgradItem>* items, int* nlayers) {
   FRX_CHECK_ARG(jobs && njobs > 0, "wgrad_group: no jobs");
+  int next_layer = 0;
   const int target = group_chunks_per_item();
   const int scatter_chunks = 128;
   // (layer, split) groups stream the same pixel range: keep each on ONE XCD (block b runs on XCD b % 8, item p is
@@ -415,24 +432,35 @@ static int group_build(const frx_wgrad_job* jobs, int njobs, std::vector<WgradAr
     splits = cdiv(g.nchunks, a.chunks_per_split);
     a.splits = splits;
     if (layers) layers->push_back(a);
+    const int lmain = next_layer++;
+    int lgram = -1;
+    if (j.gram || j.xsum) {
+      WgradArgs ag; WgradGeom gg;
+      if (int rc = gram_args(j, ag, gg)) return rc;
+      ag.chunks_per_split = a.chunks_per_split; ag.splits = splits;      // the same pixel ranges as the main layer's splits
+      if (layers) layers->push_back(ag);
+      lgram = next_layer++;
+    }
     const long cost = (long)a.chunks_per_split * (g.bt == 128 ? 4 : 1);
     for (int sp = 0; sp < splits; ++sp) {
       int best = 0;
       for (int x = 1; x < 8; ++x) if (load[x] < load[best]) best = x;
+      if (lgram >= 0) { xl[best].push_back(WgradItem{lgram, sp, 0, 0}); load[best] += cost; }      // (next to the tiles that stream the same x)
       // ... unless the layer has few pixels and many tiles (layer4: 4096 pixels, up to 144 tiles per split): its operands
       // are small and L2-resident anyway, and a whole (layer, split) group on one list leaves the eight lists unbalanced
       // (the launch ends with the longest).  Those tiles go round-robin over the XCDs (upper list 563 -> 513 us).
       if (g.nchunks <= scatter_chunks) {
         int q = 0;
         for (int tap = 0; tap < g.taps; ++tap)
-          for (int t = 0; t < a.tilesCo * a.tilesCi; ++t, ++q) { xl[(best + q) & 7].push_back(WgradItem{li, sp, t, tap}); load[(best + q) & 7] += cost; }
+          for (int t = 0; t < a.tilesCo * a.tilesCi; ++t, ++q) { xl[(best + q) & 7].push_back(WgradItem{lmain, sp, t, tap}); load[(best + q) & 7] += cost; }
         continue;
       }
       for (int tap = 0; tap < g.taps; ++tap)
-        for (int t = 0; t < a.tilesCo * a.tilesCi; ++t) xl[best].push_back(WgradItem{li, sp, t, tap});
+        for (int t = 0; t < a.tilesCo * a.tilesCi; ++t) xl[best].push_back(WgradItem{lmain, sp, t, tap});
       load[best] += cost * g.tiles;
     }
   }
+  if (nlayers) *nlayers = next_layer;
   size_t longest = 0;
   for (auto& v : xl) longest = v.size() > longest ? v.size() : longest;
   if (items) {
@@ -444,18 +472,19 @@ static int group_build(const frx_wgrad_job* jobs, int njobs, std::vector<WgradAr
 }
 
 extern "C" int64_t frx_wgrad_group_bytes(const frx_wgrad_job* jobs, int njobs) {
-  const int n = group_build(jobs, njobs, nullptr, nullptr);
+  int nl = 0;
+  const int n = group_build(jobs, njobs, nullptr, nullptr, &nl);
   if (n < 0) return n;
-  return (int64_t)group_items_offset(njobs) + (int64_t)n * (int64_t)sizeof(WgradItem);
+  return (int64_t)group_items_offset(nl) + (int64_t)n * (int64_t)sizeof(WgradItem);
 }
 
 extern "C" int frx_wgrad_group_plan(int device, frx_stream_t stream, const frx_wgrad_job* jobs, int njobs, void* table_host,
-                                    void* table_dev, int64_t table_bytes, int* nitems, int* small_tiles) {
-  FRX_CHECK_ARG(table_host && table_dev && nitems && small_tiles, "wgrad_group_plan: NULL pointer");
+                                    void* table_dev, int64_t table_bytes, int* nitems, int* small_tiles, int* nlayers) {
+  FRX_CHECK_ARG(table_host && table_dev && nitems && small_tiles && nlayers, "wgrad_group_plan: NULL pointer");
   std::vector<WgradArgs> layers; std::vector<WgradItem> items;
-  const int n = group_build(jobs, njobs, &layers, &items);
+  const int n = group_build(jobs, njobs, &layers, &items, nlayers);
   if (n < 0) return n;
-  const size_t off = group_items_offset(njobs), need = off + items.size() * sizeof(WgradItem);
+  const size_t off = group_items_offset(*nlayers), need = off + items.size() * sizeof(WgradItem);
   FRX_CHECK_ARG((size_t)table_bytes >= need, "wgrad_group_plan: table needs %zu bytes, got %ld", need, (long)table_bytes);
   FRX_ENTER(device);
   // host image first, then ONE stream-ordered copy: nothing here synchronises, and the copy is ordered against whatever
@@ -471,14 +500,67 @@ extern "C" int frx_wgrad_group_plan(int device, frx_stream_t stream, const frx_w
   return FRX_OK;
 }
 
-extern "C" int frx_wgrad_group_run(int device, frx_stream_t stream, int dtype, void* table_dev, int njobs, int nitems,
+extern "C" int frx_wgrad_group_run(int device, frx_stream_t stream, int dtype, void* table_dev, int nlayers, int nitems,
                                    int small_tiles) {
   FRX_CHECK_ARG(dtype == FRX_F32 || dtype == FRX_BF16, "wgrad_group_run: dtype");
-  FRX_CHECK_ARG(table_dev && njobs > 0 && nitems > 0, "wgrad_group_run: bad args");
+  FRX_CHECK_ARG(table_dev && nlayers > 0 && nitems > 0, "wgrad_group_run: bad args");
   FRX_ENTER(device);
   return launch_wgrad_grouped((hipStream_t)stream, dtype, (const WgradArgs*)table_dev,
-                              (const WgradItem*)((const char*)table_dev + group_items_offset(njobs)), nitems, small_tiles != 0,
-                              (int*)((char*)table_dev + group_counters_offset(njobs)));
+                              (const WgradItem*)((const char*)table_dev + group_items_offset(nlayers)), nitems, small_tiles != 0,
+                              (int*)((char*)table_dev + group_counters_offset(nlayers)));
+}
+
+// ---- closing a DECOMPOSED weight gradient: dW = alpha (.) A + beta (.) (W G) + gam (x) s
+// For a 1x1 conv whose output gradient is the BatchNorm backward dy = alpha*dz + beta*y + gam of (dz, y), y = x W^T:
+//   dW[co][ci] = sum_m dy[m,co] x[m,ci] = alpha_co * A[co][ci] + beta_co * sum_cj W[co][cj] G[cj][ci] + gam_co * s[ci]
+// with A = dz^T x (in dw already), G = x^T x and s = column sums of x (frx_wgrad_group: `gram`, `xsum`).  One launch for
+// every listed layer; the last block of a layer to finish zeroes that layer's G and s for the next step.
+namespace frx {
+template <typename T>
+__global__ __launch_bounds__(256) void k_wgrad_gram_finish(const int64_t* __restrict__ table, int n) {
+  int e = 0;
+  for (int i = 1; i < n; ++i) e = ((int64_t)blockIdx.x >= table[i * 8 + 7]) ? i : e;
+  const int64_t* t = table + e * 8;
+  float* dw = (float*)t[0];
+  const T* w = (const T*)t[1];
+  float* G = (float*)t[2];
+  float* s = (float*)t[3];
+  const float* coef = (const float*)t[4];
+  const int Co = (int)t[5], Ci = (int)(t[6] & 0xffffffff);
+  int* counter = (int*)(G + (long)Ci * Ci);                 // (one int behind the layer's G: frx_wgrad_gram_bytes)
+  const int local = (int)((int64_t)blockIdx.x - t[7]);
+  const long idx = (long)local * 256 + threadIdx.x;
+  if (idx < (long)Co * Ci) {
+    const int co = (int)(idx / Ci), ci = (int)(idx - (long)co * Ci);
+    float acc = 0.f;
+    for (int cj = 0; cj < Ci; ++cj) acc = fmaf((float)w[(long)co * Ci + cj], G[(long)cj * Ci + ci], acc);
+    dw[idx] = fmaf(coef[co], dw[idx], fmaf(coef[Co + co], acc, coef[2 * Co + co] * s[ci]));
+  }
+  // the layer's last block zeroes G and s (every block has consumed them: the loads above feed the store)
+  __shared__ int last;
+  __syncthreads();
+  const int nblk = (Co * Ci + 255) / 256;
+  if (threadIdx.x == 0) {
+    const int k = __hip_atomic_fetch_add(counter, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    last = (k == nblk - 1);
+    if (last) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads();
+  if (last) {
+    for (int i = threadIdx.x; i < Ci * Ci; i += 256) G[i] = 0.f;
+    for (int i = threadIdx.x; i < Ci; i += 256) s[i] = 0.f;
+  }
+}
+}  // namespace frx
+
+extern "C" int frx_wgrad_gram_finish(int device, frx_stream_t stream, int dtype, int n, const int64_t* table_dev, int total_blocks) {
+  FRX_CHECK_ARG(dtype == FRX_F32 || dtype == FRX_BF16, "wgrad_gram_finish: dtype");
+  FRX_CHECK_ARG(n > 0 && table_dev && total_blocks > 0, "wgrad_gram_finish: bad args");
+  FRX_ENTER(device);
+  if (dtype == FRX_BF16) hipLaunchKernelGGL(k_wgrad_gram_finish<bf16_t>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, table_dev, n);
+  else hipLaunchKernelGGL(k_wgrad_gram_finish<float>, dim3(total_blocks), dim3(256), 0, (hipStream_t)stream, table_dev, n);
+  FRX_LAUNCH_CHECK();
+  return FRX_OK;
 }
 
 extern "C" int frx_conv_wgrad(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x,

@@ -1188,6 +1188,7 @@ struct WgradArgs {
   int splits;
   unsigned xbytes, ybytes;  // sizes of X and dY (dY2) in bytes: buffer-load bounds
   int variant;              // k_wgrad_grouped: WGV_* bits selecting the instantiation for this layer
+  float* xsum;              // GRAM jobs (YM == 2): [Ci] column sums of the staged X operand, added with atomics
 };
 
 // XOR swizzle of the 32-byte slot inside a pixel row so the 8 pixel rows a half-wave touches
@@ -1205,7 +1206,12 @@ enum { WG_POINTWISE = 0, WG_GENERAL = 1, WG_STEM = 2 };
 constexpr int WGRAD_SMEM = 2 * 2 * 32 * 256;       // bytes of LDS a 128 x 128 tile's two stages take (bf16 and fp32 alike)
 
 // One (co tile, ci tile, tap, pixel split) work item; all four indices block-uniform (SGPRs).
-template <typename T, int BT, int WMODE, bool PRO, bool YPRO>   // BT x BT output tile (co x ci)
+// YM: the dY operand -- 0 as stored; 1 (YPRO) the BN backward alpha*dz + beta*y + gam of two tensors; 2 (GRAM) the X operand
+// itself, prologue included: the tile then holds G = sum_m x[m,:]^T x[m,:] (Ci <= BT: one tile), and the block also adds the
+// column sums of x into a.xsum.  What G and the sums are for: the weight gradient of a 1x1 conv whose dy is the BN backward
+// of (dz, y) splits into  alpha * (dz^T x) + beta * (W G) + gam (x) sum(x)  because y = x W^T is linear in x -- the second
+// full-width tensor y never has to be read (frx_wgrad_gram_finish closes it).
+template <typename T, int BT, int WMODE, bool PRO, int YM>   // BT x BT output tile (co x ci)
 __device__ __forceinline__ void wgrad_block(const WgradArgs& a, int split, int tile, int tap, char* smem) {
   constexpr int VEC = TT<T>::VEC;
   constexpr int KP = (sizeof(T) == 2) ? 32 : 16;   // pixels per K-chunk
@@ -1214,6 +1220,8 @@ __device__ __forceinline__ void wgrad_block(const WgradArgs& a, int split, int t
   constexpr int LD = (KP * CPR) / 256;             // 16-byte loads per thread per operand
   constexpr int WT = BT / 2, F = WT / 16;          // 2x2 waves
   constexpr int PD = 3;                            // register ring depth (chunks in flight)
+  constexpr bool YPRO = YM == 1, GRAM = YM == 2;
+  static_assert(!GRAM || WMODE == WG_POINTWISE, "gram jobs: 1x1 / stride 1");
   static_assert(LD >= 1 && 256 % CPR == 0, "tile shape");
   static_assert(2 * 2 * KP * RB <= WGRAD_SMEM, "LDS budget");
 
@@ -1287,8 +1295,11 @@ __device__ __forceinline__ void wgrad_block(const WgradArgs& a, int split, int t
   // `while` here put two divergent loops into every K-chunk of the 3x3 layers)
   const int step_n = KP / hw, step_h = (KP % hw) / a.Wo, step_w = (KP % hw) % a.Wo;
 
-  uint4 ry[PD][LD], rx[PD][LD];
+  uint4 ry[GRAM ? 1 : PD][LD], rx[PD][LD];
   uint4 ry2[YPRO ? PD : 1][LD];
+  float xs_acc[GRAM ? VEC : 1];        // GRAM: this thread's running column sums (its 16-byte channel group, its rows)
+#pragma unroll
+  for (int e = 0; e < (GRAM ? VEC : 1); ++e) xs_acc[e] = 0.f;
   unsigned rmask[PD];     // WG_GENERAL / WG_STEM: bit i = the gathered X row of load i is inside the image
 
   auto issue_chunk = [&](int kc, auto slot_tag) {
@@ -1297,7 +1308,7 @@ __device__ __forceinline__ void wgrad_block(const WgradArgs& a, int split, int t
     const int soy = kc * KP * a.Co * (int)sizeof(T);
 #pragma unroll
     for (int i = 0; i < LD; ++i) {
-      ry[slot][i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rsrcY, yvoff[i], soy, 0));
+      if constexpr (!GRAM) ry[slot][i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rsrcY, yvoff[i], soy, 0));
       if constexpr (YPRO) ry2[slot][i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rsrcY2, yvoff[i], soy, 0));
       if constexpr (WMODE == WG_POINTWISE) {
         rx[slot][i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rsrcX, xvoff[i], kc * KP * a.Ci * (int)sizeof(T), 0));
@@ -1337,7 +1348,7 @@ __device__ __forceinline__ void wgrad_block(const WgradArgs& a, int split, int t
     for (int i = 0; i < LD; ++i) {
       const int row = row0 + RSTEP * i;
       const int off = row * RB + ((ch * 16) ^ (sizeof(T) == 2 ? tr_swz<RB>(row) : 0));
-      uint4 vy = ry[slot][i], vx = rx[slot][i];
+      uint4 vy = GRAM ? rx[slot][i] : ry[slot][i], vx = rx[slot][i];
       if constexpr (PRO) {
         vx = bn_relu_vec<T>(vx, psc, psh, a.in_relu);
         if constexpr (WMODE != WG_POINTWISE) {
@@ -1352,8 +1363,22 @@ __device__ __forceinline__ void wgrad_block(const WgradArgs& a, int split, int t
           if (kc * KP + row >= a.M) vy = make_uint4(0, 0, 0, 0);
         }
       }
-      *reinterpret_cast<uint4*>(Ys + off) = vy;
-      *reinterpret_cast<uint4*>(Xs + off) = vx;
+      if constexpr (GRAM) {        // one staged tile serves as both operands; its column sums on the way
+        if constexpr (TAIL && !PRO) { if (kc * KP + row >= a.M) vx = make_uint4(0, 0, 0, 0); }      // (rows past M load as 0 already; kept for symmetry)
+        *reinterpret_cast<uint4*>(Ys + off) = vx;
+        if constexpr (sizeof(T) == 2) {
+          const unsigned* w = reinterpret_cast<const unsigned*>(&vx);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { xs_acc[2 * e] += __uint_as_float(w[e] << 16); xs_acc[2 * e + 1] += __uint_as_float(w[e] & 0xffff0000u); }
+        } else {
+          const float* w = reinterpret_cast<const float*>(&vx);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) xs_acc[e] += w[e];
+        }
+      } else {
+        *reinterpret_cast<uint4*>(Ys + off) = vy;
+        *reinterpret_cast<uint4*>(Xs + off) = vx;
+      }
     }
   };
 
@@ -1366,7 +1391,7 @@ __device__ __forceinline__ void wgrad_block(const WgradArgs& a, int split, int t
   const int fr = lane & 15, fq = lane >> 4;
   auto compute_chunk = [&](int cur) {
     const char* Ys = smem + cur * (2 * KP * RB);
-    const char* Xs = Ys + KP * RB;
+    const char* Xs = GRAM ? Ys : Ys + KP * RB;
     if constexpr (sizeof(T) == 2) {
       // lane (16g + 4q + p) supplies &tile[pix0 + q][col0 + 4p]; it receives column (lane&15),
       // rows pix0..pix0+3.  Two reads (pix0 = 8g, 8g+4) build the k = 8g..8g+7 fragment.
@@ -1470,6 +1495,20 @@ __device__ __forceinline__ void wgrad_block(const WgradArgs& a, int split, int t
   }
 
   FRX_STAMP(2);
+  if constexpr (GRAM) {
+    // column sums: the 256 / CPR threads that share a channel group meet in LDS (the stages are free: last barrier passed)
+    float* red = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) red[(row0 * CPR + ch) * VEC + e] = xs_acc[e];
+    __syncthreads();
+    if (tid < CPR * VEC && a.xsum) {
+      float t = 0.f;
+      for (int r = 0; r < RSTEP; ++r) t += red[r * CPR * VEC + tid];
+      const int c = ci0 + tid;
+      if (c < a.Ci) atomicAdd(a.xsum + c, t);
+    }
+    __syncthreads();
+  }
   const int ldw = (WMODE == WG_STEM) ? 32 : a.Ci;   // elements per (co, r, s-row) line of dW
   const bool atomic = a.splits > 1;
 #pragma unroll
@@ -1492,7 +1531,7 @@ __device__ __forceinline__ void wgrad_block(const WgradArgs& a, int split, int t
     }
 }
 
-template <typename T, int BT, int WMODE, bool PRO, bool YPRO>
+template <typename T, int BT, int WMODE, bool PRO, int YM>
 __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
   FRX_STAMP(0);
   __shared__ __attribute__((aligned(16))) char smem[WGRAD_SMEM];
@@ -1504,7 +1543,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
   const int rest = __builtin_amdgcn_readfirstlane(blockIdx.x / a.splits);
   const int tile = __builtin_amdgcn_readfirstlane(rest % (a.tilesCo * a.tilesCi));
   const int tap = __builtin_amdgcn_readfirstlane(rest / (a.tilesCo * a.tilesCi));
-  wgrad_block<T, BT, WMODE, PRO, YPRO>(a, split, tile, tap, smem);
+  wgrad_block<T, BT, WMODE, PRO, YM>(a, split, tile, tap, smem);
 #ifdef FRX_DBG_TIMES
   __builtin_amdgcn_s_waitcnt(0);
   FRX_STAMP(3);
@@ -1516,7 +1555,7 @@ __global__ __launch_bounds__(256, 2) void k_wgrad(WgradArgs a) {
 // loads its next item, per-launch floors (53 of them) and the tails of 128-block launches disappear, and
 // one list balances layers of very different size across the whole GPU.
 struct WgradItem { int layer, split, tile, tap; };
-enum { WGV_BT128 = 1, WGV_GENERAL = 2, WGV_STEM = 4, WGV_PRO = 8, WGV_YPRO = 16 };   // WgradArgs::variant bits
+enum { WGV_BT128 = 1, WGV_GENERAL = 2, WGV_STEM = 4, WGV_PRO = 8, WGV_YPRO = 16, WGV_GRAM = 32 };   // WgradArgs::variant bits
 
 // SMALL: a list whose layers all take the 64 x 64 tile (layer1 and the stem: the HBM-bound end of the network) gets its own
 // instantiation -- under 128 registers, four blocks per CU -- instead of the register budget of the widest 128 x 128 variant.
@@ -1554,7 +1593,15 @@ __global__ __launch_bounds__(256, SMALL ? 4 : 2) void k_wgrad_grouped(const Wgra
               tap = __builtin_amdgcn_readfirstlane(w.tap);
     const int v = __builtin_amdgcn_readfirstlane(a.variant);
 #define FRX_WGV(BT_, WM_, PRO_, YP_) wgrad_block<T, BT_, WM_, PRO_, YP_>(a, split, tile, tap, smem)
-    if (v & WGV_STEM) FRX_WGV(64, WG_STEM, false, false);
+    if (v & WGV_STEM) FRX_WGV(64, WG_STEM, false, 0);
+    else if (v & WGV_GRAM) {       // (1x1 / stride 1, one tile: G = x^T x and the column sums of x)
+      if (!SMALL && (v & WGV_BT128)) {
+        if constexpr (SMALL) {}
+        else if (v & WGV_PRO) FRX_WGV(128, WG_POINTWISE, true, 2); else FRX_WGV(128, WG_POINTWISE, false, 2);
+      } else {
+        if (v & WGV_PRO) FRX_WGV(64, WG_POINTWISE, true, 2); else FRX_WGV(64, WG_POINTWISE, false, 2);
+      }
+    }
     else if (!SMALL && (v & WGV_BT128)) {
       if constexpr (SMALL) {}
       else if ((v & WGV_GENERAL) && (v & WGV_YPRO)) { if (v & WGV_PRO) FRX_WGV(128, WG_GENERAL, true, true); else FRX_WGV(128, WG_GENERAL, false, true); }

@@ -42,7 +42,7 @@ class WgradJob(C.Structure):
     """frx_wgrad_job (include/frx.h)"""
     _fields_ = [("d", ConvDesc), ("x", C.c_void_p), ("in_scale", C.c_void_p), ("in_shift", C.c_void_p),
                 ("in_relu", C.c_int32), ("dy", C.c_void_p), ("pro_y", C.c_void_p), ("pro_coef", C.c_void_p),
-                ("dw", C.c_void_p)]
+                ("dw", C.c_void_p), ("gram", C.c_void_p), ("xsum", C.c_void_p)]
 
 
 def library_path() -> str:
@@ -93,7 +93,8 @@ _SIGS = {
     "frx_conv_patch_mode": (C.c_int, [C.POINTER(ConvDesc), C.c_int]),
     "frx_wgrad_group_bytes": (C.c_int64, [C.POINTER(WgradJob), C.c_int]),
     "frx_wgrad_group_plan": (C.c_int, [C.c_int, _P, C.POINTER(WgradJob), C.c_int, _P, _P, C.c_int64, C.POINTER(C.c_int),
-                                       C.POINTER(C.c_int)]),
+                                       C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "frx_wgrad_gram_finish": (C.c_int, [C.c_int, _P, C.c_int, C.c_int, _P, C.c_int]),
     "frx_wgrad_group_run": (C.c_int, [C.c_int, _P, C.c_int, _P, C.c_int, C.c_int, C.c_int]),
     "frx_conv_dgrad_bn": (C.c_int, [C.c_int, _P, C.POINTER(ConvDesc), _P, _P, _P, _P, C.POINTER(DgradFuse)]),
     "frx_conv_wgrad_bn": (C.c_int, [C.c_int, _P, C.POINTER(ConvDesc), _P, _P, _P, C.c_int, _P, _P, _P, _P]),

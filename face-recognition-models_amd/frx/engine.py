@@ -57,6 +57,8 @@ class ConvSpec:
     tot_b: object = None
     patch_dgrad: bool = False    # 3x3 / stride 1 on the patch-mode kernel: its input gradient evaluates the BN backward itself
     x_norm: torch.Tensor = None  # 3x3 / stride 1 on the patch-mode kernel (training): the forward keeps relu(bn(x)) for the weight gradient
+    gram: torch.Tensor = None    # decomposed weight gradient (_gram_ok): x^T x [Ci*Ci] + the finish launch's counter
+    xsum: torch.Tensor = None    #   and the column sums of x [Ci]
 
     @property
     def Ho(self):
@@ -249,6 +251,10 @@ class ResNet50Engine:
             if pm and pm == ops._igemm_tile(c2.desc)[0]:
                 c2.x_norm = torch.zeros_like(b.conv1.y)      # (the grouped lists: -78 us per step)
             b.dyc = {c.name: torch.zeros_like(c.y) for c in (b.conv1, b.conv3, b.down) if c is not None and self._keeps_dy(c)}
+            for c in (b.conv3, b.down):
+                if c is not None and self._gram_ok(c):      # decomposed weight gradient: x^T x (+ the finish launch's counter), sum(x)
+                    c.gram = torch.zeros(c.Ci * c.Ci + 1, device=self.device)
+                    c.xsum = torch.zeros(c.Ci, device=self.device)
         self._train_ready = True
         if self.grouped_wgrad:
             self._plan_wgrad_groups()
@@ -752,6 +758,17 @@ class ResNet50Engine:
         self._wgrad(s, self.xin, self.dy_stem)     # (padding tap / channel slots are not written)
 
     # ------------------------------------------------------------------ weight gradients
+    def _gram_ok(self, c):
+        """1x1 / stride-1 convs whose weight gradient runs DECOMPOSED in the grouped lists: the ones that would otherwise read
+        dz AND the raw output y (two full-width tensors) -- dy = alpha*dz + beta*y + gam with y = x W^T linear in x gives
+        dW = alpha (.) dz^T x + beta (.) W (x^T x) + gam (x) sum(x): the y read (103 MB per layer1 conv3 at batch 256)
+        becomes a Ci x Ci side product of the x the list streams anyway.  Layer1's conv3 and projection (Ci = 64): same
+        box, alternating, 6.246 / 6.246 / 6.246 -> 6.211 / 6.178 / 6.176 ms per step, the layer1 + stem list 376 -> 344 us.
+        Layer2's conv3 (Ci = 128: a 128 x 128 side tile per pixel split) LOSES what it saves (that list 281 -> 322 us):
+        not decomposed (profiles/r04_wgrad_gram_ab.txt).  FRX_WGRAD_GRAM (0 / 64 / 128): the measurement's switch."""
+        lim = int(os.environ.get("FRX_WGRAD_GRAM", "64"))
+        return self.grouped_wgrad and c.k == 1 and c.stride == 1 and not self._keeps_dy(c) and c.Ci <= min(lim, 128)
+
     def _wgrad_job(self, c, x, dy, x_bn=None, pro_y=None, pro_coef=None):
         pro = {} if x_bn is None else dict(in_scale=self._bn(self.bn_scale, x_bn), in_shift=self._bn(self.bn_shift, x_bn),
                                            in_relu=True)
@@ -789,6 +806,8 @@ class ResNet50Engine:
                     continue
                 if self._keeps_dy(c):
                     jobs.append(self._wgrad_job(c, x, b.dyc[c.name], x_bn=xb))
+                elif self._gram_ok(c):
+                    jobs.append(dict(self._wgrad_job(c, x, dz, x_bn=xb), gram=c.gram, xsum=c.xsum, wk=c.wk, coef=coef))
                 else:
                     jobs.append(self._wgrad_job(c, x, dz, x_bn=xb, pro_y=c.y, pro_coef=coef))
             if b.conv2.x_norm is not None:

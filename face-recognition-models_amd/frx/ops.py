@@ -383,17 +383,26 @@ def conv_wgrad(d, x, dy, dw, in_scale=None, in_shift=None, in_relu=False):
 
 class WgradGroup:
     """a planned frx_wgrad_group table (device) plus everything that must outlive it"""
-    __slots__ = ("table", "njobs", "nitems", "small_tiles", "dtype", "flops", "nbytes", "keep")
+    __slots__ = ("table", "njobs", "nitems", "small_tiles", "dtype", "flops", "nbytes", "keep", "finish")
 
 
 def wgrad_group_plan(dtype, jobs):
-    """jobs: dicts with d (ConvDesc), x, dy, dw and optionally in_scale / in_shift / in_relu / pro_y / pro_coef.
+    """jobs: dicts with d (ConvDesc), x, dy, dw and optionally in_scale / in_shift / in_relu / pro_y / pro_coef -- or, for a
+    DECOMPOSED job (include/frx.h: frx_wgrad_job.gram), gram / xsum buffers plus wk (the kernel-format weight) and coef (the
+    BatchNorm-backward coefficients [3][Co]): the group then carries the table of its closing launch (wgrad_group_run runs it).
     The tensors' addresses are captured: they must stay allocated (and in place) while the group is used."""
     arr = (_lib.WgradJob * len(jobs))()
+    fin, blk = [], 0
     for i, j in enumerate(jobs):
         arr[i] = _lib.WgradJob(j["d"], _pv(j["x"]), _pv(j.get("in_scale")), _pv(j.get("in_shift")),
                                int(bool(j.get("in_relu", False))), _pv(j["dy"]), _pv(j.get("pro_y")),
-                               _pv(j.get("pro_coef")), _pv(j["dw"]))
+                               _pv(j.get("pro_coef")), _pv(j["dw"]), _pv(j.get("gram")), _pv(j.get("xsum")))
+        if j.get("gram") is not None:
+            d = j["d"]
+            assert j["gram"].numel() == d.Ci * d.Ci + 1 and j["xsum"].numel() == d.Ci
+            fin.append((j["dw"].data_ptr(), j["wk"].data_ptr(), j["gram"].data_ptr(), j["xsum"].data_ptr(), j["coef"].data_ptr(),
+                        d.Co, d.Ci, blk))
+            blk += (d.Co * d.Ci + 255) // 256
     nbytes = _lib.lib().frx_wgrad_group_bytes(arr, len(jobs))
     if nbytes < 0:
         raise FrxError("frx_wgrad_group_bytes: " + _lib.lib().frx_last_error().decode())
@@ -403,20 +412,29 @@ def wgrad_group_plan(dtype, jobs):
     # the table is assembled in pinned host memory and copied by one stream-ordered asynchronous copy (enqueue-only,
     # like every libfrx call); the host image has to outlive that copy, so it stays with the group
     host = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
-    n, small = C.c_int(0), C.c_int(0)
+    n, small, nl = C.c_int(0), C.c_int(0), C.c_int(0)
     check(_lib.lib().frx_wgrad_group_plan(_dev(g.table), _stream(g.table), arr, len(jobs), C.c_void_p(host.data_ptr()),
-                                          _p(g.table), nbytes, C.byref(n), C.byref(small)), "frx_wgrad_group_plan")
-    g.njobs, g.nitems, g.small_tiles, g.dtype = len(jobs), n.value, small.value, dtype
+                                          _p(g.table), nbytes, C.byref(n), C.byref(small), C.byref(nl)), "frx_wgrad_group_plan")
+    g.njobs, g.nitems, g.small_tiles, g.dtype = nl.value, n.value, small.value, dtype      # (njobs: the table's layer count)
     g.flops = sum(conv_flops(j["d"]) for j in jobs)
     g.nbytes = sum(conv_bytes(j["d"], n_out=2 if j.get("pro_y") is not None else 1, wbytes=j["dw"].numel() * 4) for j in jobs)
     g.keep = [t for j in jobs for t in j.values() if isinstance(t, torch.Tensor)] + [host]
+    g.finish = None
+    if fin:
+        g.finish = (torch.tensor(fin, dtype=torch.int64, device=dev), len(fin), blk)
     return g
 
 
 def wgrad_group_run(g):
-    _timed(f"k_wgrad_grouped<{_dt_name(g.dtype)}>", g.flops, g.table, lambda: check(
-        _lib.lib().frx_wgrad_group_run(_dev(g.table), _stream(g.table), g.dtype, _p(g.table), g.njobs, g.nitems,
-                                       g.small_tiles), "frx_wgrad_group_run"), nbytes=g.nbytes)
+    """the list's launch and, if it holds decomposed jobs, their closing launch (frx_wgrad_gram_finish: the BatchNorm-backward
+    coefficient arrays named at plan time must be final by now)"""
+    def run():
+        check(_lib.lib().frx_wgrad_group_run(_dev(g.table), _stream(g.table), g.dtype, _p(g.table), g.njobs, g.nitems,
+                                             g.small_tiles), "frx_wgrad_group_run")
+        if g.finish is not None:
+            tab, n, blocks = g.finish
+            check(_lib.lib().frx_wgrad_gram_finish(_dev(tab), _stream(tab), g.dtype, n, _p(tab), blocks), "frx_wgrad_gram_finish")
+    _timed(f"k_wgrad_grouped<{_dt_name(g.dtype)}>", g.flops, g.table, run, nbytes=g.nbytes)
 
 
 def conv_dgrad_stat_rows(d):

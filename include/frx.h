@@ -299,6 +299,13 @@ typedef struct frx_wgrad_job {
   const void* pro_y;
   const float* pro_coef;
   float* dw;
+  /* DECOMPOSED job (both set, pro_y / pro_coef NULL; 1x1, stride 1, Ci <= 128): the weight gradient of a conv whose dy is the
+   * BatchNorm backward alpha*dz + beta*y + gam of (dz, y) WITHOUT reading y: dw accumulates the plain dz^T x, gram [Ci*Ci]
+   * the matrix x^T x and xsum [Ci] the column sums of x (x after its prologue); frx_wgrad_gram_finish closes
+   * dW = alpha (.) dw + beta (.) (W gram) + gam (x) xsum, because y = x W^T is linear in x.  gram must be followed by one
+   * zeroed int32 (the finish launch's completion counter) and, like xsum, start at zero. */
+  float* gram;
+  float* xsum;
 } frx_wgrad_job;
 int64_t frx_wgrad_group_bytes(const frx_wgrad_job* jobs, int njobs);          /* size of the device table; < 0: error */
 /* Enqueue-only like every other call: the table is built in `table_host` (table_bytes of PINNED host memory owned by the
@@ -308,9 +315,15 @@ int64_t frx_wgrad_group_bytes(const frx_wgrad_job* jobs, int njobs);          /*
  * so group such layers into a list of their own.  The table also holds the launch's eight item-draw counters (one per XCD;
  * every launch leaves them at zero): one table serves one launch at a time. */
 int frx_wgrad_group_plan(int device, frx_stream_t stream, const frx_wgrad_job* jobs, int njobs, void* table_host,
-                         void* table_dev, int64_t table_bytes, int* nitems, int* small_tiles);
-int frx_wgrad_group_run(int device, frx_stream_t stream, int dtype, void* table_dev, int njobs, int nitems,
+                         void* table_dev, int64_t table_bytes, int* nitems, int* small_tiles, int* nlayers);
+/* nlayers: as returned by the plan (njobs + the decomposed jobs' internal x^T x layers) */
+int frx_wgrad_group_run(int device, frx_stream_t stream, int dtype, void* table_dev, int nlayers, int nitems,
                         int small_tiles);
+/* closes the decomposed jobs of a list after frx_wgrad_group_run (and after the BatchNorm backward coefficients are final):
+ * table_dev [n][8] int64 = {dw, kernel-format weight [Co][Ci] in the compute dtype (what the forward multiplied by), gram,
+ * xsum, coef [3][Co] (alpha | beta | gam: frx_bn_bwd_finalize*), Co, Ci, index of the layer's first block (256 weights per
+ * block)}; total_blocks = sum of ceil(Co*Ci / 256).  gram and xsum are zeroed again when the layer is done. */
+int frx_wgrad_gram_finish(int device, frx_stream_t stream, int dtype, int n, const int64_t* table_dev, int total_blocks);
 
 /* ---------------------------------------------------------------- backbone: BatchNorm / ReLU / residual / pools
  * Replace nn.BatchNorm2d x53 (train: batch statistics + running-stat update, momentum 0.1, eps 1e-5;

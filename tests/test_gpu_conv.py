@@ -584,6 +584,56 @@ def test_grouped_wgrad_matches_per_layer(dtype):
 
 
 @pytest.mark.parametrize("dtype", [0, 1], ids=["f32", "bf16"])
+def test_decomposed_wgrad_equals_the_two_tensor_form(dtype):
+    """Round 4: the weight gradient of a 1x1 conv whose dy is the BatchNorm backward alpha*dz + beta*y + gam, WITHOUT reading y
+    (frx_wgrad_job.gram / xsum + frx_wgrad_gram_finish): dW = alpha (.) dz^T x + beta (.) W (x^T x) + gam (x) sum(x), because
+    y = x W^T.  Against the two-tensor form (pro_y / pro_coef) of the same list, and both against a float64 evaluation of
+    sum_m dy[m, co] x[m, ci] on the same tensors: the decomposed form must be at least as close to float64 as the form it
+    replaces.  y is the library's own forward of x (bf16: rounded as the training step stores it).  Shapes: layer1 / layer2
+    conv3 and layer1's projection at reduced batch, a ragged pixel count, both tile sizes, with and without the prologue."""
+    from frx import ops
+    T = ops.TORCH_DT[dtype]
+    g = torch.Generator().manual_seed(5)
+    shapes = [(64, 256, 28, 6, True), (128, 512, 14, 9, True), (64, 256, 28, 4, False), (64, 128, 9, 3, True), (128, 128, 5, 7, False)]
+    two, dec, refs = [], [], []
+    for (Ci, Co, H, N, pro) in shapes:
+        d = ops.conv_desc(dtype, N, H, H, Ci, Co, 1, 1, 1, 0)
+        x = _mk(dtype, N, H, H, Ci, seed=Ci + Co + H).to(DEV)
+        w = (_mk(dtype, Co, 1, 1, Ci, seed=Co) * Ci ** -0.5).to(T).to(DEV)
+        sc, sh = (torch.rand(Ci, generator=g) + 0.5).to(DEV), (torch.randn(Ci, generator=g) * 0.3).to(DEV)
+        kw = dict(in_scale=sc, in_shift=sh, in_relu=True) if pro else {}
+        y = torch.empty(N, H, H, Co, dtype=T, device=DEV)
+        ops.conv_fwd(d, x, w, y, **kw)
+        dz = _mk(dtype, N, H, H, Co, seed=Ci + 3).to(DEV)
+        coef = torch.cat([torch.rand(Co, generator=g) + 0.5, torch.randn(Co, generator=g) * 0.2, torch.randn(Co, generator=g) * 0.1]).to(DEV)
+        two.append(dict(d=d, x=x, dy=dz, pro_y=y, pro_coef=coef, dw=torch.zeros(Co, 1, 1, Ci, device=DEV), **kw))
+        dec.append(dict(d=d, x=x, dy=dz, dw=torch.zeros(Co, 1, 1, Ci, device=DEV), gram=torch.zeros(Ci * Ci + 1, device=DEV),
+                        xsum=torch.zeros(Ci, device=DEV), wk=w, coef=coef, **kw))
+        # float64: the staged operands exactly as the kernels see them (x after its prologue, rounded to T)
+        xs = x.double()
+        if pro:
+            xs = torch.relu(torch.addcmul(sh.double(), xs, sc.double()).to(T).double()) if dtype == 1 else torch.relu(xs * sc.double() + sh.double())
+        al, be, ga = coef.double().view(3, Co)
+        dy = al * dz.double() + be * y.double() + ga
+        refs.append(torch.einsum("nhwo,nhwi->oi", dy, xs))
+    g2, gd = ops.wgrad_group_plan(dtype, two), ops.wgrad_group_plan(dtype, dec)
+    assert gd.finish is not None and gd.njobs == 2 * len(dec) and g2.finish is None
+    ops.wgrad_group_run(g2)
+    for rep in range(2):                    # twice: the finish launch leaves gram / xsum zeroed for the next step
+        for j in dec:
+            j["dw"].zero_()
+        ops.wgrad_group_run(gd)
+        torch.cuda.synchronize()
+        for (Ci, Co, H, N, pro), a, b, r in zip(shapes, two, dec, refs):
+            assert float(b["gram"].abs().max()) == 0.0 and float(b["xsum"].abs().max()) == 0.0
+            e2 = ((a["dw"].double().view(Co, Ci) - r).norm() / r.norm()).item()
+            ed = ((b["dw"].double().view(Co, Ci) - r).norm() / r.norm()).item()
+            print(f"{Ci}->{Co} H{H} N{N} pro={pro} {'bf16' if dtype else 'f32'}: rel err vs float64: two-tensor {e2:.2e}, decomposed {ed:.2e}")
+            assert ed < (2e-3 if dtype == 1 else 2e-5), (Ci, Co, ed)
+            assert ed < 2 * e2 + (1e-3 if dtype == 1 else 1e-6), (Ci, Co, ed, e2)
+
+
+@pytest.mark.parametrize("dtype", [0, 1], ids=["f32", "bf16"])
 def test_block_merge_mask_bits(dtype):
     from frx import ops
     rows, Cc = 37 * 49, 256
