@@ -4,10 +4,10 @@
 // CE model_utils.py:556,179; top-k metrics.py:3-16).
 //
 // Numerics: logits are cosines x 64 and the parity bar is 1e-3, which bf16 operands miss by
-// 35x.  Two GEMM kernels: the f32-input MFMA (v_mfma_f32_32x32x2_f32: bit-for-bit an fp32
-// fma chain; the default, and what the fp32 parity mode runs) and, under frx_head_desc.flags bit 4, the
-// split-bf16 scheme of SURVEY H2 (k_gemm_bf16x3: three bf16 MFMA passes on hi / lo halves of each fp32
-// operand: < 1e-4 on the logits at ~5x the rate), which the bf16 engine selects.
+// 35x: the GEMMs run on the f32-input MFMA (v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 fma
+// chain).  The split-bf16 scheme of SURVEY H2 (three bf16 MFMA passes on hi / lo halves of each operand) was built
+// twice -- 64 x 64 tiles in round 3, 128 x 128 eight-wave tiles in round 4 -- correct on every golden and no faster
+// (these products are bound by staging and latency, not by the matrix pipe): removed.
 #include "frx_common.h"
 #include <type_traits>
 
@@ -144,180 +144,13 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
   }
 }
 
-// ------------------------------------------------------------------------------------------
-// The same GEMM on the bf16 matrix cores by operand SPLITTING: every fp32 operand a is staged as hi = bf16(a) and
-// lo = bf16(a - hi) (16 significant bits together), and a.b is accumulated in fp32 as hi.hi + hi.lo + lo.hi -- three
-// v_mfma_f32_16x16x32_bf16 per tile pair instead of sixteen v_mfma_f32_16x16x4_f32: ~5x the exact-fp32 rate.  The dropped
-// lo.lo term and the rounding of lo bound the relative error of each product by ~2^-16; for cosines (|sum| <= 1 of
-// products of unit vectors) the measured logit error is < 1e-4 (tests/test_gpu_head.py), inside the 1e-3 bar the exact
-// fp32 GEMM exists for.  Selected per head by frx_head_desc.flags bit 4 (the bf16 engine sets it; goldens run both).
-// Same arguments, operand layouts, K split and epilogue as k_gemm_f32.  64x64 tile, 32-deep K steps, 4 waves (2x2 of
-// 32x32 = 2x2 MFMA blocks).  Staging layout by the operand's memory order (no transposes in registers):
-//   K contiguous  -> [x][32 k] rows of 64 bytes, 16-byte chunks XOR-swizzled (swz64), fragments by ds_read_b128
-//   x contiguous  -> [k][64 x] rows of 128 bytes, fragments by the transposing ds_read_b64_tr_b16 (as the weight gradients)
-// ------------------------------------------------------------------------------------------
-constexpr int HBK = 32;
-__device__ __forceinline__ int h_swz64(int row) { return (0x1320 >> (((row >> 2) & 3) * 4)) & 3; }
-__device__ __forceinline__ int h_trswz(int row) { return ((((row >> 1) & 1) | (((row >> 3) & 1) << 1)) << 5); }     // [k][64 x] rows of 128 B
-
-__device__ __forceinline__ void split_bf16(const float v[4], s16x4& hi, s16x4& lo) {
-  bf16x4 h, l;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) { h[j] = (bf16_t)v[j]; l[j] = (bf16_t)(v[j] - (float)h[j]); }
-  hi = *reinterpret_cast<s16x4*>(&h); lo = *reinterpret_cast<s16x4*>(&l);
-}
-// stage one 16-deep half (k offset kh = 0 / 16 inside the 32-deep step) of an operand tile; planes: hi at P, lo at P + 4096
-template <bool MC>
-__device__ __forceinline__ void split_store(char* P, const float v[4], int xi, int ki, int kh) {
-  s16x4 hi, lo;
-  split_bf16(v, hi, lo);
-  int off;
-  if (MC) {                       // [k][x]: 4 consecutive x at row k
-    const int k = kh + ki;
-    off = k * 128 + ((xi * 2) ^ h_trswz(k));
-  } else {                        // [x][k]: 4 consecutive k in row x
-    const int k = kh + ki;
-    off = xi * 64 + (((k >> 3) ^ h_swz64(xi)) << 4) + (k & 7) * 2;
-  }
-  *reinterpret_cast<s16x4*>(P + off) = hi;
-  *reinterpret_cast<s16x4*>(P + 4096 + off) = lo;
-}
-// the 16x16x32 fragment (lane l: row x0 + (l & 15), k = 8 (l >> 4) .. + 7) of plane P
-template <bool MC>
-__device__ __forceinline__ bf16x8 split_frag(const char* P, int x0, int lane) {
-  if (MC) {
-    // lane (16 g + 4 q + p) supplies &tile[k = 8 g + 4 h + q][x0 + 4 p]; it receives x = x0 + (lane & 15), rows 8 g + 4 h .. + 3
-    const int g = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
-    s16x4 r[2];
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int k = 8 * g + 4 * h + q;
-      r[h] = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(P + k * 128 + (((x0 + 4 * p) * 2) ^ h_trswz(k))));
-    }
-    typedef short s16x8 __attribute__((ext_vector_type(8)));
-    s16x8 v = __builtin_shufflevector(r[0], r[1], 0, 1, 2, 3, 4, 5, 6, 7);
-    return *reinterpret_cast<bf16x8*>(&v);
-  } else {
-    const int row = x0 + (lane & 15), ch = lane >> 4;
-    return *reinterpret_cast<const bf16x8*>(P + row * 64 + ((ch ^ h_swz64(row)) << 4));
-  }
-}
-
-template <bool AMC, bool BNC>
-__global__ __launch_bounds__(256, 2) void k_gemm_bf16x3(GemmArgs g) {
-  // per stage: A hi | A lo | B hi | B lo, 4 KB each (64 x 32 bf16)
-  __shared__ __attribute__((aligned(16))) char S[2][4][4096];
-  const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
-  const int kbeg = blockIdx.z * g.ksplit_len;
-  const int kend = min(g.K, kbeg + g.ksplit_len);
-  const int nsteps = (kend - kbeg + HBK - 1) / HBK;
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int wm = wave >> 1, wn = wave & 1;
-  f32x4 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-  // Register ring of RD K-steps: the fp32 tile loads run RD - 1 steps ahead of the split + LDS store that consumes them.
-  // (The blocks of these skinny GEMMs -- 256 rows of features against 10^4 .. 10^5 classes, K = 512 -- are few and short:
-  // with the loads one step ahead every step exposed a full memory round trip, 45 us for 2.8 GFLOP.)
-  constexpr int RD = 3;
-  float va[RD][2][4], vb[RD][2][4];
-  int ax = 0, ak = 0, bx = 0, bk = 0;
-  auto load_step = [&](int step, auto slot_tag) {
-    constexpr int sl = decltype(slot_tag)::value;
-    const int k0 = kbeg + step * HBK;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      gemm_load_tile<AMC>(g.A, g.lda, m0, g.M, k0 + 16 * h, kend, g.a_kscale, va[sl][h], ax, ak);
-      gemm_load_tile<BNC>(g.B, g.ldb, n0, g.N, k0 + 16 * h, kend, nullptr, vb[sl][h], bx, bk);
-    }
-  };
-  auto store_step = [&](int buf, auto slot_tag) {
-    constexpr int sl = decltype(slot_tag)::value;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      split_store<AMC>(S[buf][0], va[sl][h], ax, ak, 16 * h);
-      split_store<BNC>(S[buf][2], vb[sl][h], bx, bk, 16 * h);
-    }
-  };
-  auto compute = [&](int buf) {
-    bf16x8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      ah[i] = split_frag<AMC>(S[buf][0], wm * 32 + 16 * i, lane);
-      al[i] = split_frag<AMC>(S[buf][1], wm * 32 + 16 * i, lane);
-      bh[i] = split_frag<BNC>(S[buf][2], wn * 32 + 16 * i, lane);
-      bl[i] = split_frag<BNC>(S[buf][3], wn * 32 + 16 * i, lane);
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        // small terms first: the cross products are ~2^-8 of hi.hi
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-      }
-  };
-  using R0 = std::integral_constant<int, 0>;
-  using R1 = std::integral_constant<int, 1>;
-  using R2 = std::integral_constant<int, 2>;
-  // step s lives in ring slot s % 3 and LDS stage s & 1; one ring step: MFMAs of step s, loads of step s + 3 into the slot
-  // step s just left, split + store of step s + 1, barrier
-  auto ring_step = [&](int sidx, auto cur_tag, auto nxt_tag) {
-    compute(sidx & 1);
-    if (sidx + RD < nsteps) load_step(sidx + RD, cur_tag);
-    if (sidx + 1 < nsteps) store_step((sidx + 1) & 1, nxt_tag);
-    __syncthreads();
-  };
-  load_step(0, R0{});
-  if (1 < nsteps) load_step(1, R1{});
-  if (2 < nsteps) load_step(2, R2{});
-  store_step(0, R0{});
-  __syncthreads();
-  for (int sidx = 0; sidx < nsteps; sidx += 3) {
-    ring_step(sidx, R0{}, R1{});
-    if (sidx + 1 < nsteps) ring_step(sidx + 1, R1{}, R2{});
-    if (sidx + 2 < nsteps) ring_step(sidx + 2, R2{}, R0{});
-  }
-  // C/D map of the 16x16 MFMA: col = lane & 15 (n), row = (lane >> 4) * 4 + reg (m)
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int n = n0 + wn * 32 + 16 * j + (lane & 15);
-    if (n >= g.N) continue;
-    const float cs = g.col_scale ? g.col_scale[n] : 1.f;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int m = m0 + wm * 32 + 16 * i + (lane >> 4) * 4 + r;
-        if (m < g.M) {
-          float v = acc[i][j][r] * cs;
-          if (g.row_scale) v *= g.row_scale[m];
-          float* dst = g.C + (long)m * g.ldc + n;
-          if (g.atomic_out) atomicAdd(dst, v); else *dst = v;
-        }
-      }
-  }
-}
-
-static int launch_gemm(hipStream_t st, GemmArgs g, int ksplit, bool split_bf16_ok = false) {
+static int launch_gemm(hipStream_t st, GemmArgs g, int ksplit) {
   if (ksplit < 1) ksplit = 1;
-  int len = (int)round_up((size_t)cdiv(g.K, ksplit), split_bf16_ok ? HBK : GBK);
+  int len = (int)round_up((size_t)cdiv(g.K, ksplit), GBK);
   g.ksplit_len = len;
   ksplit = cdiv(g.K, len);
   g.atomic_out = ksplit > 1 ? 1 : g.atomic_out;
   dim3 grid(cdiv(g.N, GBN), cdiv(g.M, GBM), ksplit), block(256);
-  if (split_bf16_ok && g.ksplit_len % HBK == 0) {
-    if (g.a_mcontig && g.b_ncontig) hipLaunchKernelGGL((k_gemm_bf16x3<true, true>), grid, block, 0, st, g);
-    else if (g.a_mcontig && !g.b_ncontig) hipLaunchKernelGGL((k_gemm_bf16x3<true, false>), grid, block, 0, st, g);
-    else if (!g.a_mcontig && g.b_ncontig) hipLaunchKernelGGL((k_gemm_bf16x3<false, true>), grid, block, 0, st, g);
-    else hipLaunchKernelGGL((k_gemm_bf16x3<false, false>), grid, block, 0, st, g);
-    FRX_LAUNCH_CHECK();
-    return FRX_OK;
-  }
   if (g.a_mcontig && g.b_ncontig) hipLaunchKernelGGL((k_gemm_f32<true, true>), grid, block, 0, st, g);
   else if (g.a_mcontig && !g.b_ncontig) hipLaunchKernelGGL((k_gemm_f32<true, false>), grid, block, 0, st, g);
   else if (!g.a_mcontig && g.b_ncontig) hipLaunchKernelGGL((k_gemm_f32<false, true>), grid, block, 0, st, g);
@@ -1228,7 +1061,7 @@ extern "C" int frx_head_fwd_cos(int device, frx_stream_t stream, const frx_head_
   g.B = w; g.M = d->N; g.N = d->C; g.K = d->D;
   if (w_is_cd(d->kind)) { g.b_ncontig = 0; g.ldb = d->D; } else { g.b_ncontig = 1; g.ldb = d->C; }
   g.C = W.cbuf; g.ldc = W.Cpad; g.row_scale = W.xinv; g.col_scale = W.winv;
-  if (int rc = launch_gemm(st, g, 1, (d->flags & 16) != 0)) return rc;
+  if (int rc = launch_gemm(st, g, 1)) return rc;
   float* tys = ty_sum_out ? ty_sum_out : W.tysum;
   const HeadConst hc = make_const(d);
 #define FRX_TY(K) hipLaunchKernelGGL(k_head_ty<K>, dim3(1), dim3(256), 0, st, hc, W.cbuf, d->N, (long)W.Cpad, d->C, labels, W.ty, tys)
@@ -1258,7 +1091,7 @@ extern "C" int frx_head_vpl_prepare(int device, frx_stream_t stream, const frx_h
   g.A = x; g.lda = d->D; g.a_mcontig = 0;
   g.B = mem; g.M = d->N; g.N = d->C; g.K = d->D; g.b_ncontig = 0; g.ldb = d->D;
   g.C = W.cbuf2; g.ldc = W.Cpad; g.row_scale = W.xinv; g.col_scale = W.minv;
-  if (int rc = launch_gemm(st, g, 1, (d->flags & 16) != 0)) return rc;
+  if (int rc = launch_gemm(st, g, 1)) return rc;
   hipLaunchKernelGGL(k_vpl_blend, dim3(d->N), dim3(256), 0, st, W.cbuf, (const float*)W.cbuf2, (const float*)life, labels,
                      d->C, (long)W.Cpad, d->p[0]);
   hipLaunchKernelGGL(k_head_ty<FRX_VPL>, dim3(1), dim3(256), 0, st, make_const(d), W.cbuf, d->N, (long)W.Cpad, d->C, labels, W.ty, W.tysum);
@@ -1474,10 +1307,10 @@ static int head_bwd_impl(int device, frx_stream_t stream, const frx_head_desc* d
     const int tiles = cdiv(d->N, GBM) * cdiv(d->D, GBN);
     int ksplit = tiles >= 512 ? 1 : cdiv(1024, tiles);
     ksplit = ksplit > cdiv(d->C, 64) ? cdiv(d->C, 64) : ksplit;
-    if (int rc = launch_gemm(st, g, ksplit, (d->flags & 16) != 0)) return rc;
+    if (int rc = launch_gemm(st, g, ksplit)) return rc;
     if (vpl) {                       // + (dC * a*lamda, non-target) . M^   into the same accumulator
       g.A = W.gbuf2; g.a_kscale = W.minv; g.B = state_t;
-      if (int rc = launch_gemm(st, g, ksplit, (d->flags & 16) != 0)) return rc;
+      if (int rc = launch_gemm(st, g, ksplit)) return rc;
     }
   }
   hipLaunchKernelGGL(k_norm_bwd_rows, dim3(cdiv(d->N, 4)), dim3(256), 0, st, x, (const float*)W.dxh,
@@ -1498,7 +1331,7 @@ static int head_bwd_impl(int device, frx_stream_t stream, const frx_head_desc* d
       g.B = W.gbuf; g.ldb = W.Cpad; g.b_ncontig = 1;
       g.M = d->D; g.N = d->C; g.ldc = d->C;
     }
-    if (int rc = launch_gemm(st, g, 1, (d->flags & 16) != 0)) return rc;
+    if (int rc = launch_gemm(st, g, 1)) return rc;
   }
   if (cd)
     hipLaunchKernelGGL(k_norm_bwd_rows, dim3(cdiv(d->C, 4)), dim3(256), 0, st, w, (const float*)W.dwh,

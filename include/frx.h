@@ -78,9 +78,7 @@ typedef struct frx_head_desc {
                         VPL: bit 1 = norm_training_flag, the memory is in use (criterion.py:671-679)
                         SPHERE: bit 2 = read the annealing lambda from state_t[0] instead of `lamb` (a captured
                                 hipGraph then follows criterion.py:58-60 without re-capture)
-                        bit 4 = the three GEMMs of the head run on the bf16 matrix cores by operand splitting (each fp32
-                                operand as hi + lo bf16, hi.hi + hi.lo + lo.hi accumulated in fp32: relative error of a
-                                product <= ~2^-16, logits within 1e-4 of the exact-fp32 MFMA chain used otherwise)
+                        bit 4 = reserved (rounds 3-4: a split-bf16 form of the head's GEMMs, measured no faster, removed)
                         bit 3 = class-sharded mode (ARC / COS / SPHERE / CURR / MV_*): this descriptor is the column
                                 shard [class_offset, class_offset + C) of a wider head; N counts the rows of the
                                 GATHERED batch and labels stay global (see "class-sharded head" below) */

@@ -15,7 +15,7 @@ K = int(sys.argv[4]) if len(sys.argv) > 4 else 20
 DEV = torch.device("cuda:0")
 kid = E.HEAD_KINDS[kind]
 s_, m_ = E.HEAD_DEFAULTS[kid]
-FLAGS = E.HEAD_FLAG_DEFAULTS.get(kid, 0) | (16 if os.environ.get("FRX_HEAD_GEMM", "f32") == "bf16x3" else 0)      # bit 4: split-bf16 GEMMs
+FLAGS = E.HEAD_FLAG_DEFAULTS.get(kid, 0)
 ctx = ops.HeadContext(kid, N, 512, C, s_, m_, 0.01, device=DEV, p=E.HEAD_P_DEFAULTS.get(kid, ()), flags=FLAGS)
 g = torch.Generator().manual_seed(0)
 cd = kid in ops.W_CD_KINDS
@@ -36,4 +36,4 @@ for _ in range(K): o = step()
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / K
 fl = 6.0 * N * 512 * C
-print(f"{kind} N={N} C={C} gemm={'bf16x3' if FLAGS & 16 else 'f32'}: {ms:.3f} ms per fwd+bwd, {fl / ms / 1e9:.1f} TFLOP/s algorithmic, loss {o['loss'].item():.4f}")
+print(f"{kind} N={N} C={C} {ms:.3f} ms per fwd+bwd, {fl / ms / 1e9:.1f} TFLOP/s algorithmic, loss {o['loss'].item():.4f}")

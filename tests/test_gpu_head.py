@@ -18,26 +18,13 @@ KINDS = {"arcface": H.ARC, "cosface": H.COS, "sphereface": H.SPHERE, "curricular
 LOGIT_TOL = 1e-3          # north-star tolerance on logits (cosine x 64)
 
 
-_SPLIT = False
-
-
-@pytest.fixture(params=["f32", "bf16x3"], autouse=True)
-def gemm_kind(request):
-    """every test of this file runs on both head GEMM kernels: the exact-fp32 MFMA chain and the split-bf16 one
-    (frx_head_desc.flags bit 4: hi / lo halves, three bf16 MFMA passes) -- the same goldens, the same 1e-3 bars"""
-    global _SPLIT
-    _SPLIT = request.param == "bf16x3"
-    yield
-    _SPLIT = False
-
-
 def _run(kind, x, w, y, hyper, t0=0.0, lamb=0.0, want_logits=True):
     from frx import ops
     dev = torch.device("cuda:0")
     N, D = x.shape
     Cc = w.shape[0] if H.weight_is_cd(kind) else w.shape[1]
     ctx = ops.HeadContext(kind, N, D, Cc, hyper.s, float(hyper.m), hyper.momentum, device=dev,
-                          flags=(1 if (kind == H.ARC and hyper.easy_margin) else 0) | (16 if _SPLIT else 0))
+                          flags=(1 if (kind == H.ARC and hyper.easy_margin) else 0))
     xd = torch.from_numpy(np.ascontiguousarray(x)).to(dev)
     wd = torch.from_numpy(np.ascontiguousarray(w)).to(dev)
     yd = torch.from_numpy(np.asarray(y).astype(np.int64)).to(dev)
@@ -136,7 +123,7 @@ def test_head_full_size_properties(name, N, Cc):
     x = torch.randn(N, D, generator=g)
     y = torch.randint(0, Cc, (N,), generator=g)
     hy = H.HeadHyper.default(kind)
-    ctx = ops.HeadContext(kind, N, D, Cc, hy.s, float(hy.m), hy.momentum, device=dev, flags=16 if _SPLIT else 0)
+    ctx = ops.HeadContext(kind, N, D, Cc, hy.s, float(hy.m), hy.momentum, device=dev)
     t = torch.zeros(1, device=dev)
     o = ops.head_forward(ctx, x.to(dev), w.to(dev), y.to(dev), state_t=t, want_logits=True)
     z = o["logits"].double().cpu()
