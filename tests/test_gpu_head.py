@@ -35,6 +35,51 @@ def _run(kind, x, w, y, hyper, t0=0.0, lamb=0.0, want_logits=True):
     return o, dx.cpu().numpy(), dw.cpu().numpy(), float(t.item())
 
 
+@pytest.mark.parametrize("name,N,Cc", [("arcface", 32, 100), ("cosface", 37, 1000), ("mv_am", 64, 333), ("mv_arc", 16, 64),
+                                       ("arcface", 256, 10575), ("cosface", 256, 10575), ("arcface", 64, 85742)])
+def test_fused_forward_equals_the_row_sweep(name, N, Cc):
+    """Round 4 (north_star: cosine GEMM + fused row-max / exp / sum epilogue): without [N, C] outputs the forward of ARC / COS /
+    MV takes the fused path -- target cosines as N dot products, the GEMM's epilogue leaves per-tile (max, sum-exp, rank)
+    partials, one combine launch closes loss / lse / top-k -- against the row sweep over the stored cosines that the same
+    call runs when cos_s / logits are asked for: lse and loss to fp32 rounding of the sums, top-k counts identical, and the
+    backward (which reads the cosines the GEMM wrote, the target element being the dot product's own value) identical."""
+    from frx import ops
+    kinds = {"arcface": H.ARC, "cosface": H.COS, "mv_am": H.MV_AM, "mv_arc": H.MV_ARC}
+    kind = kinds[name]
+    hy = hyper_for(name) if name in ("arcface", "cosface") else None
+    rng = np.random.RandomState(N + Cc)
+    x = rng.randn(N, 512).astype(np.float32)
+    w = (rng.randn(Cc, 512) if H.weight_is_cd(kind) else rng.randn(512, Cc)).astype(np.float32) * 0.05
+    y = rng.randint(0, Cc, N)
+    y[0], y[-1] = 0, Cc - 1
+    if H.weight_is_cd(kind):                                     # a few rows with a REAL target (cosine near 0.7: the margin branch)
+        for i in range(0, N, 5):
+            w[y[i]] = 0.7 * x[i] / np.linalg.norm(x[i]) * np.linalg.norm(w[y[i]]) + 0.3 * w[y[i]]
+    dev = torch.device("cuda:0")
+    s_, m_ = (hy.s, float(hy.m)) if hy is not None else (32.0, 0.35)
+    p = (1.12,) if hy is None else ()
+    res = []
+    for want in (True, False):
+        ctx = ops.HeadContext(kind, N, 512, Cc, s_, m_, 0.01, device=dev, p=p)
+        xd, wd, yd = torch.from_numpy(x).to(dev), torch.from_numpy(w).to(dev), torch.from_numpy(y.astype(np.int64)).to(dev)
+        o = ops.head_forward(ctx, xd, wd, yd, want_logits=want)
+        dx, dw = ops.head_backward(ctx, xd, wd, yd)
+        torch.cuda.synchronize()
+        res.append((o, dx.clone(), dw.clone()))
+    (oa, dxa, dwa), (ob, dxb, dwb) = res
+    assert ob["logits"] is None and oa["logits"] is not None
+    assert abs(oa["loss"].item() - ob["loss"].item()) < 2e-5 * abs(oa["loss"].item())
+    assert (oa["lse"] - ob["lse"]).abs().max().item() < 2e-5 * oa["lse"].abs().max().item()
+    assert torch.equal(oa["topk"], ob["topk"]), (oa["topk"], ob["topk"])
+    assert torch.equal(oa["norms"], ob["norms"])
+    # an independent top-k from the full outputs of the row-sweep run
+    top5 = oa["cos_s"].topk(5, dim=1).indices
+    yd = torch.from_numpy(y.astype(np.int64)).to(dev)
+    assert int(ob["topk"][0]) == int((top5[:, 0] == yd).sum()) and int(ob["topk"][1]) == int((top5 == yd[:, None]).any(1).sum())
+    for a, b in ((dxa, dxb), (dwa, dwb)):
+        assert ((a - b).norm() / (a.norm() + 1e-30)).item() < 1e-5
+
+
 def _ill(kind, cos_s, y, norms):
     ty = cos_s[np.arange(len(y)), y] / (64.0 if kind != H.SPHERE else norms.reshape(-1))
     return (np.abs(ty) > 1 - 1e-5) & (kind in (H.ARC, H.CURR))

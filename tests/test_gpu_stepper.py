@@ -43,7 +43,12 @@ def test_graph_replay_equals_the_eager_step(kind):
         # random head puts every target cosine within 0.05 of the k boundary cos = 0 (m = 2): two trajectories that differ by
         # the order of their fp32 atomics then flip k on some row by step 3 (4 of 24 runs 2-4 % apart).
         # Deterministic instead of loose: one batch with labels 0..N-1 whose class rows start ON the batch's own features
-        # (target cosine 1, k = 0), checked below to stay far from every k boundary through the four steps.
+        # (target cosine 1, k = 0), checked below to stay far from every k boundary through the four steps.  (Measured with
+        # that in place: at lr 0.01 the two trajectories still sat 2.5 % apart at step 3 -- SphereFace's logits are scaled by
+        # the feature NORM, not by a fixed s, so the fp32-atomics-order difference of two N = 8 trajectories shows in the loss
+        # sooner than with the normalised heads; k flips were not the cause.  A fifth of the step size keeps two correct
+        # trajectories inside 2e-2 for four steps; a wrong lambda or a stale graph input is O(1).)
+        lr = 0.002
         c = _eng(kind, N, C, ops.F32)
         x0 = batches[0][0]
         c.net.training = True
