@@ -29,6 +29,43 @@ void note_igemm_launch(int bm, int bn, int waves, int kc, int ns, int mode, int 
   memcpy(t_last_launch, v, sizeof(v));
 }
 
+// The fc layer (nn.Linear(2048, 512) on the pooled features, backbones.py:17; bf16 speed mode): M = batch rows are too few for
+// the tiled kernel -- 32 tiles of 64 x 64, each a chain of 64 K-chunks: 21.6 us for 0.54 GFLOP (round 3).  Here one block owns
+// ONE 16 x 16 output tile and its four waves split the contraction four ways; the MFMA fragments come straight from global
+// memory (a lane's 16 bytes are 8 consecutive k of one row: no staging), 8 chunks in flight per wave; the four partial tiles
+// meet in LDS in a fixed order (bit-reproducible).  512 blocks for 256 x 512 outputs.
+__global__ __launch_bounds__(256) void k_fc_fwd_bf16(const bf16_t* __restrict__ x, const bf16_t* __restrict__ w, const float* __restrict__ bias,
+                                                     float* __restrict__ y, int M, int N, int K) {
+  __shared__ float red[4][16][17];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int m0 = blockIdx.y * 16, n0 = blockIdx.x * 16;
+  const int fr = lane & 15, fq = lane >> 4;
+  const int row = m0 + fr < M ? m0 + fr : M - 1, col = n0 + fr < N ? n0 + fr : N - 1;      // (clamped: their outputs are not stored)
+  const int kq = K / 4, kbeg = wave * kq;            // this wave's quarter of the contraction (host: K % 128 == 0)
+  const bf16_t* xp = x + (long)row * K + kbeg + 8 * fq;
+  const bf16_t* wp = w + (long)col * K + kbeg + 8 * fq;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int k0 = 0; k0 < kq; k0 += 256) {
+    bf16x8 a[8], b[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = k0 + 32 * u < kq ? k0 + 32 * u : 0;
+      a[u] = *reinterpret_cast<const bf16x8*>(xp + k);
+      b[u] = *reinterpret_cast<const bf16x8*>(wp + k);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (k0 + 32 * u < kq) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b[u], a[u], acc, 0, 0, 0);      // D[row = n][col = m]
+  }
+  // C/D map: col = lane & 15 (here: m), row = (lane >> 4) * 4 + reg (here: n)
+#pragma unroll
+  for (int r = 0; r < 4; ++r) red[wave][fr][fq * 4 + r] = acc[r];
+  __syncthreads();
+  const int t = threadIdx.x, ml = t >> 4, nl = t & 15;
+  if (m0 + ml < M && n0 + nl < N)
+    y[(long)(m0 + ml) * N + n0 + nl] = (((red[0][ml][nl] + red[1][ml][nl]) + red[2][ml][nl]) + red[3][ml][nl]) + bias[n0 + nl];
+}
+
 static int launch_igemm(hipStream_t st, ConvArgs a, int dtype) {
   t_last_launch[11] = a.R * a.S * a.Kc;                 // contraction length (note_igemm_launch fills in the rest)
   FRX_CHECK_ARG(a.Ncol % 64 == 0, "igemm: output channel count %d must be a multiple of 64", a.Ncol);
@@ -102,6 +139,14 @@ static int launch_igemm(hipStream_t st, ConvArgs a, int dtype) {
     FRX_CHECK_ARG(!(a.dy_out && (a.R != 1 || a.S != 1)),
                   "conv_dgrad_bn: pro_dy_out on a 3x3 needs the patch-mode launch (BN-backward prologue, masked-statistics epilogue, no "
                   "addend; partial-statistics rows only where frx_conv_tile's row tile is frx_conv_patch_mode's)");
+  }
+  if (epi == EPI_FC && dtype == FRX_BF16 && pointwise && a.mode == MODE_FWD && a.bias && a.out_f32 && !has_pro && a.M <= 4096 &&
+      a.Kc % 128 == 0 && a.Kc * 2 % 16 == 0) {
+    note_igemm_launch(16, 16, 4, 64, 0, MODE_FWD, 0, EPI_FC, 0, 0, 0);
+    hipLaunchKernelGGL(k_fc_fwd_bf16, dim3(cdiv(a.Ncol, 16), cdiv(a.M, 16)), dim3(256), 0, st, (const bf16_t*)a.X, (const bf16_t*)a.W, a.bias,
+                       (float*)a.Y, a.M, a.Ncol, a.Kc);
+    FRX_LAUNCH_CHECK();
+    return FRX_OK;
   }
   if (a.mode == MODE_STEM) return launch_igemm_stem(st, a, dtype, c, grid, epi);
   if (a.mode == MODE_DGRAD)
