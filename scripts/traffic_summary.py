@@ -15,6 +15,8 @@ def label(name):
         stage = "patch" if mode in (3, 4) else (f"dma{ns}" if ns else "ring")
         return (f"k_igemm<{'bf16' if m.group(1)=='DF16b' else 'f32'},{bm}x{bn}x{wm * wn}w,kc{kc},{MODE[mode]},pro={PRO[pro]},epi={EPI[epi]}"
                 f"{'+add' if add else ''},{stage}{',persist' if persist else ''}{',stagewaves' if spec else ''}>")
+    if "k_wgrad_grouped" in name:          # (both instantiations, mangled or demangled: frx/ops.py labels them as one class)
+        return "k_wgrad_grouped<f32>" if re.search(r"k_wgrad_groupedIf|k_wgrad_grouped<float", name) else "k_wgrad_grouped<bf16>"
     m = re.search(r"k_wgradI(DF16b|f)Li(\d+)E", name)
     if m: return f"k_wgrad<{'bf16' if m.group(1)=='DF16b' else 'f32'},{m.group(2)}>"
     return re.sub(r"\(.*", "", name)[:60]
