@@ -1,0 +1,343 @@
+// Row-resident pointwise input gradient (bf16): the conv1-type input gradients of a bottleneck block -- few contraction
+// channels (the block's middle width, 64..512), many output channels (4x that), and an epilogue that streams three
+// full-width tensors (the identity branch's gradient, the merge-ReLU mask, the raw output of the previous block's last
+// BatchNorm for sum(dz * xhat)).  Reference ops replaced: autograd's backward of torchvision Bottleneck.conv1 + the block
+// merge + the previous block's bn3 (main_code/utils/backbones.py:16-18 builds the ResNet-50; model_utils.py:185 runs it).
+//
+// k_igemm gives such a launch one 128 x 128 tile per block: fill the prologue tables, 2-16 K-chunks, then an epilogue that
+// only now asks for its 64 KB of operands -- a serial chain of ~13 us per tile (profiles/r03_igemm_stamps.txt), the BN-backward
+// prologue re-evaluated for every column tile (8x at layer3), and 784 tiles on 512 slots.  Here a persistent block owns a
+// contiguous range of (64-pixel row block, 128-channel column tile) items, row block major:
+//   * the transformed operand dy = alpha * dz + beta * y + gam of a row block is built ONCE and stays in LDS;
+//   * the weights of a column tile come straight from L2 into the MFMA fragment registers (a lane's 16 bytes are 8
+//     consecutive k of one output channel: no staging), each wave owning 32 of the 128 columns and all 64 pixels;
+//   * the epilogue operands of item i + 1 are fetched by LDS-DMA -- every lane fetches exactly the 16 bytes it will
+//     consume, so the lane-linear image needs no layout and no barrier -- while item i's epilogue arithmetic and item
+//     i + 1's MFMAs run;
+//   * the per-channel statistics accumulate in an LDS table (each column has one owning lane) and reach the replicated
+//     totals as one burst of atomics per block; sum(dz * xhat) is closed there as invstd * (sum(dz * y) - mean * sum(dz)).
+// Ranges are split evenly (items * b / blocks), so every block runs the same count +- 1.
+#include "conv_launch.h"
+
+namespace frx {
+
+constexpr int PWR_BM = 64, PWR_BN = 128, PWR_NT = 512;
+constexpr int PWR_EBYTES = 2 * 4 * 4 * 1024;       // one ring slot of epilogue operands: [tensor (addend, raw y)][row fragment][wave] x 1 KiB (lane-linear)
+
+unsigned pw_rows_lds(int Kc, int Ncol, int ring) { return (unsigned)(PWR_BM * Kc * 2 + ring * PWR_EBYTES + 3 * Kc * 4 + 2 * Ncol * 4); }
+
+// (hipcc may park a block-uniform descriptor in vector registers when scalar registers run short; the DMA wants it in SGPRs)
+__device__ __forceinline__ u32x4_t pwr_sgpr4(u32x4_t r) {
+  u32x4_t o;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) o[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)r[i]);
+  return o;
+}
+
+// XOR swizzle of the 16-byte slot index of a [64 rows][RB bytes] image read with ds_read_b128 in the MFMA fragment pattern
+// (row = lane & 15, slot = 4 ks + (lane >> 4)): the 16 lanes of a service group ({fq 0: fr 0-3, 12-15; fq 1: fr 4-11}, ...)
+// land on 16 distinct 16-byte positions of the 256-byte bank row.
+// The per-item barrier orders LDS traffic only.  __syncthreads() is fence + barrier: its fence drains vmcnt -- the compute
+// waves' output stores and, worse, every DMA a loader has in flight (the ring would be one item deep whatever its size).
+__device__ __forceinline__ void pwr_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int RB> __device__ __forceinline__ int pwr_swz(int row) {
+  if constexpr (RB >= 256) return row & 15;
+  else return (row >> 1) & 7;
+}
+
+// One block per CU, eight waves: waves 0-3 compute (wave w: all 64 pixels x columns 32 w .. 32 w + 31 of the item's 128),
+// waves 4-7 only LOAD -- wave 4 + w keeps RING - 1 items of wave w's epilogue operands in flight by LDS-DMA, lane for lane
+// the 16-byte pieces lane l of wave w will consume (the lane-linear image needs no layout).  A loader's instruction stream
+// holds nothing but those DMAs, so its counted vmcnt is exact; one barrier per item hands a filled slot to the compute
+// waves and the slot they just finished back to the loaders.
+template <int KCH, bool ADD, int RING>
+__global__ __launch_bounds__(PWR_NT, 2) void k_pw_rows_dgrad(ConvArgs a, int items, int col_tiles) {
+  typedef bf16_t T;
+  constexpr int RB = KCH * 2, SPR = KCH / 8, KS = KCH / 32;
+  constexpr int CT = 256;                               // compute threads
+  constexpr int ALD = KS, RSTEP = CT / SPR;             // 16-byte loads per compute thread, tensor and row block; rows between them
+  constexpr int NE = ADD ? 8 : 4;                       // DMA instructions per item and loader wave
+  constexpr bool APF = KCH <= 128;                      // the next row block's raw operand rows are requested an item ahead (registers)
+  constexpr unsigned OOB = 0x80000000u;
+  static_assert(KCH == 64 || KCH == 128 || KCH == 256, "middle widths served");
+  static_assert(RING >= 2 && RING <= 5, "ring slots");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;
+  char* sE = sA + PWR_BM * RB;
+  float* sTab = reinterpret_cast<float*>(sE + RING * PWR_EBYTES);  // [KCH / 8][alpha, beta, gam][8]
+  float* sStat = sTab + 3 * KCH;                                  // [2][Ncol]: sum dz, sum dz * y
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const bool loader = wave >= 4;
+  const int cw = wave & 3;                              // the compute wave (whose operands a loader fetches)
+  const int fr = lane & 15, fq = lane >> 4;
+  const int lo = (int)((long)items * blockIdx.x / gridDim.x), hi = (int)((long)items * (blockIdx.x + 1) / gridDim.x);
+  if (lo >= hi) return;
+  FRX_STAMP(0);
+
+  const unsigned ybytes = (unsigned)a.M * (unsigned)a.Ncol * 2u;
+  const int Hc = (a.Ho + 1) >> 1, Wc = (a.Wo + 1) >> 1, hw = a.Ho * a.Wo;
+  auto row_offsets = [&](int m0, int n0, unsigned (&yo)[4], unsigned (&ao)[4]) {
+    const int nb = n0 + 32 * cw + 8 * fq;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + 16 * i + fr;
+      yo[i] = m < a.M ? (unsigned)((m * a.Ncol + nb) * 2) : OOB;
+      ao[i] = yo[i];
+      if (ADD && a.add_stride == 2) {
+        const int n = m / hw, rem = m - n * hw, h = rem / a.Wo, ww = rem - h * a.Wo;
+        const bool on = m < a.M && !((h | ww) & 1);
+        ao[i] = on ? (unsigned)((((n * Hc + (h >> 1)) * Wc + (ww >> 1)) * a.Ncol + nb) * 2) : OOB;
+      }
+    }
+  };
+
+  if (loader) {
+    // ---------------------------------------------------------------- loader waves
+    unsigned addbytes = ybytes;
+    if (ADD && a.add_stride == 2) addbytes = (unsigned)a.N * Hc * Wc * a.Ncol * 2u;
+    const u32x4_t rawEy = pwr_sgpr4(raw_rsrc(a.e_y, ybytes)), rawAdd = pwr_sgpr4(raw_rsrc(ADD ? a.addend : a.e_y, addbytes));
+    const unsigned ldsE = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)sE + (unsigned)cw * 1024u;
+    auto issue_dma = [&](int it) {
+      const int rb = it / col_tiles, ct = it - rb * col_tiles;
+      const unsigned slot = (unsigned)__builtin_amdgcn_readfirstlane((it - lo) % RING) * (unsigned)PWR_EBYTES;
+      unsigned yo[4], ao[4];
+      row_offsets(rb * PWR_BM, ct * PWR_BN, yo, ao);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (ADD) dma16(rawAdd, ldsE + slot + (unsigned)((0 * 4 + i) * 4096), ao[i], 0);
+        dma16(rawEy, ldsE + slot + (unsigned)((1 * 4 + i) * 4096), yo[i], 0);
+      }
+    };
+#pragma unroll
+    for (int k = 0; k < RING - 1; ++k)
+      if (lo + k < hi) issue_dma(lo + k);
+    __syncthreads();                  // (tables built)
+    __syncthreads();                  // (first row block committed)
+    int cur_rb = lo / col_tiles;
+    for (int it = lo; it < hi; ++it) {
+      // item `it` has landed once at most the DMAs of the items after it are in flight
+      if (it + RING - 2 < hi) wait_vmcnt<(RING - 2) * NE>(); else wait_vmcnt<0>();
+      pwr_barrier();                  // item `it` handed over; the compute waves are done with item it - 1: its slot is free
+      if (it + RING - 1 < hi) issue_dma(it + RING - 1);
+      const int rb = it / col_tiles;
+      if (rb != cur_rb) { pwr_barrier(); cur_rb = rb; }        // (the compute waves' barrier behind a new row block)
+    }
+  } else {
+    // ---------------------------------------------------------------- compute waves
+    const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.X), 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcX2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.X2), 0, a.xbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcDy = __builtin_amdgcn_make_buffer_rsrc(a.dy_out ? a.dy_out : const_cast<void*>(a.X), 0, a.dy_out ? a.xbytes : 0u, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, a.wbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(a.Y, 0, ybytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsrcBits = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.e_bits), 0, ybytes / 16u, 0x00020000);
+    // a row block's transformed operand -> LDS (thread: one 16-byte channel group `s`, rows row0 + RSTEP * i)
+    const int s = tid % SPR, row0 = tid / SPR;
+    const float* tab = sTab + s * 24;
+    uint4 rz[ALD], ry[ALD];
+    auto issue_rows = [&](int m0) {
+#pragma unroll
+      for (int i = 0; i < ALD; ++i) {
+        const int m = m0 + row0 + RSTEP * i;
+        const unsigned off = m < a.M ? (unsigned)((m * KCH + s * 8) * 2) : OOB;
+        rz[i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rsrcX, off, 0, 0));
+        ry[i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rsrcX2, off, 0, 0));
+      }
+    };
+    auto commit_rows = [&](int m0) {
+#pragma unroll
+      for (int i = 0; i < ALD; ++i) {
+        const int row = row0 + RSTEP * i, m = m0 + row;
+        uint4 v = affine2_vec<T>(rz[i], ry[i], tab, tab + 8, tab + 16);
+        if (m >= a.M) v = make_uint4(0, 0, 0, 0);          // (rows past M load as 0, which the affine map turns into gam)
+        u32x4_t sv; sv[0] = v.x; sv[1] = v.y; sv[2] = v.z; sv[3] = v.w;
+        __builtin_amdgcn_raw_buffer_store_b128(sv, rsrcDy, m < a.M ? (unsigned)((m * KCH + s * 8) * 2) : OOB, 0, 0);      // (empty descriptor without dy_out)
+        *reinterpret_cast<uint4*>(sA + row * RB + ((s ^ pwr_swz<RB>(row)) << 4)) = v;
+      }
+    };
+    uint4 w[KS][2];
+    unsigned nbits[4];
+    unsigned wvoff[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) wvoff[j] = (unsigned)(((32 * wave + chan_of(j, fr)) * KCH + 8 * fq) * 2);
+    auto issue_bits = [&](int it) {
+      const int rb = it / col_tiles, ct = it - rb * col_tiles;
+      unsigned yo[4], ao[4];
+      row_offsets(rb * PWR_BM, ct * PWR_BN, yo, ao);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) nbits[i] = __builtin_amdgcn_raw_buffer_load_b8(rsrcBits, yo[i] == OOB ? OOB : (yo[i] >> 4), 0, 0);
+    };
+    auto issue_w = [&](int it) {
+      const int ct = it % col_tiles;
+      const int sw = ct * PWR_BN * KCH * 2;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) w[ks][j] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rsrcW, wvoff[j], sw + ks * 64, 0));
+    };
+
+    // set-up: the first row block, weights and mask bytes are requested before the tables are built
+    int cur_rb = lo / col_tiles;
+    issue_rows(cur_rb * PWR_BM);
+    issue_w(lo);
+    issue_bits(lo);
+    for (int c = tid; c < 2 * a.Ncol; c += CT) sStat[c] = 0.f;
+    if (a.in_scale) {
+      for (int c = tid; c < KCH; c += CT) {
+        float* t = sTab + (c >> 3) * 24 + (c & 7);
+        t[0] = a.in_scale[c]; t[8] = a.in_shift[c]; t[16] = a.pro_gam[c];
+      }
+    } else {
+      const BnTot b = bn_tot_copy(a.pro_tot);
+      bn_tot_foreach<CT>(b.tot, b.R, KCH, [&](int c, double sa, double sb) {
+        float al, be, ga;
+        bn_bwd_consts(sa, sb, b.inv_count, b.gamma[c], b.mean[c], b.invstd[c], al, be, ga);
+        float* t = sTab + (c >> 3) * 24 + (c & 7);
+        t[0] = al; t[8] = be; t[16] = ga;
+      });
+    }
+    __syncthreads();
+    commit_rows(cur_rb * PWR_BM);
+    __syncthreads();
+    FRX_STAMP(1);
+    bool rows_pending = false;
+
+    for (int it = lo; it < hi; ++it) {
+      const int rb = it / col_tiles, ct = it - rb * col_tiles;
+      const int m0 = rb * PWR_BM, n0 = ct * PWR_BN;
+      const char* sEi = sE + ((it - lo) % RING) * PWR_EBYTES + (wave * 1024 + lane * 16);
+      pwr_barrier();                      // item `it`'s operands are in its slot; every compute wave is done with item it - 1
+      if (rb != cur_rb) {                 // (block-uniform) the next row block's operand replaces this one
+        if (!rows_pending) issue_rows(m0);
+        commit_rows(m0);
+        pwr_barrier();
+        cur_rb = rb; rows_pending = false;
+      }
+      if constexpr (APF) {                // the row block after this one starts with the next item: request its rows now
+        if (ct == col_tiles - 1 && it + 1 < hi) { issue_rows(m0 + PWR_BM); rows_pending = true; }
+      }
+      f32x4 acc[4][2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        uint4 fa[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = 16 * i + fr;
+          fa[i] = *reinterpret_cast<const uint4*>(sA + row * RB + (((ks * 4 + fq) ^ pwr_swz<RB>(row)) << 4));
+        }
+        // operands swapped (weights first): D[row = channel][col = pixel] -- a lane ends up with 8 consecutive channels of a pixel
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w[ks][j]), *reinterpret_cast<bf16x8*>(&fa[i]), acc[i][j], 0, 0, 0);
+      }
+      unsigned bits[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) bits[i] = nbits[i];
+      if (it + 1 < hi) { issue_w(it + 1); issue_bits(it + 1); }
+
+      unsigned yo[4], ao[4];
+      row_offsets(m0, n0, yo, ao);
+      float csum[8], csq[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { csum[e] = 0.f; csq[e] = 0.f; }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        float v[8], yv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = acc[i][e >> 2][e & 3];
+        if constexpr (ADD) {
+          const uint4 ea = *reinterpret_cast<const uint4*>(sEi + (0 * 4 + i) * 4096);
+          const unsigned* q = reinterpret_cast<const unsigned*>(&ea);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(q[e] << 16); v[2 * e + 1] += __uint_as_float(q[e] & 0xffff0000u); }
+        }
+        {
+          const uint4 ey = *reinterpret_cast<const uint4*>(sEi + (1 * 4 + i) * 4096);
+          const unsigned* q = reinterpret_cast<const unsigned*>(&ey);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { yv[2 * e] = __uint_as_float(q[e] << 16); yv[2 * e + 1] = __uint_as_float(q[e] & 0xffff0000u); }
+        }
+        bf16x8 t;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          v[e] = ((bits[i] >> e) & 1u) ? v[e] : 0.f;
+          t[e] = (bf16_t)v[e];
+          v[e] = (float)t[e];                                   // statistics of what the next kernel reads
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<u32x4_t*>(&t), rsrcY, yo[i], 0, 0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { csum[e] += v[e]; csq[e] += v[e] * yv[e]; }
+      }
+      lane16_butterfly<8, 8>(csum, csq, fr);
+      if (fr < 8) {                       // lane (fq, fr < 8) owns column 32 wave + 8 fq + fr of every column tile: no other lane of the block adds to it
+        const int col = n0 + 32 * wave + 8 * fq + fr;
+        sStat[col] += csum[0];
+        sStat[a.Ncol + col] += csq[0];
+      }
+    }
+    FRX_STAMP(2);
+  }
+  __syncthreads();
+  const int rep = blockIdx.x & (a.stat_R - 1);
+  for (int c = tid; c < a.Ncol; c += PWR_NT) {
+    const float s1 = sStat[c], s2 = sStat[a.Ncol + c];
+    if (s1 != 0.f || s2 != 0.f) {
+      __hip_atomic_fetch_add(a.stat_tot + ((long)rep * 2 + 0) * a.Ncol + c, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_fetch_add(a.stat_tot + ((long)rep * 2 + 1) * a.Ncol + c, a.e_invstd[c] * (s2 - a.e_mean[c] * s1), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+#ifdef FRX_DBG_TIMES
+  __builtin_amdgcn_s_waitcnt(0);
+  FRX_STAMP(3);
+#endif
+}
+
+bool pw_rows_dgrad_ok(const ConvArgs& a, int dtype, int epi) {
+  if (const char* e = getenv("FRX_PW_ROWS")) { if (atoi(e) == 0) return false; }
+  const bool pw = a.mode == MODE_DGRAD && a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0 && !a.s2c;
+  return dtype == FRX_BF16 && pw && a.X2 && epi == EPI_BNBWD_OUT && a.e_bits && a.stat_tot && !a.stat_partial && !a.out_f32 &&
+         (a.Kc == 64 || a.Kc == 128 || a.Kc == 256) && a.Ncol % PWR_BN == 0 && a.Ncol >= 2 * a.Kc &&
+         (!a.addend || a.add_stride == 2 || a.add_stride == 0 || a.add_stride == 1);
+}
+
+template <int KCH, bool ADD, int RING>
+static void launch_one(hipStream_t st, const ConvArgs& a, int items, int col_tiles, unsigned lds) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw_rows_dgrad<KCH, ADD, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    attr_done = true;
+  }
+  const int grid = items < 256 ? items : 256;
+  hipLaunchKernelGGL((k_pw_rows_dgrad<KCH, ADD, RING>), dim3(grid), dim3(PWR_NT), lds, st, a, items, col_tiles);
+}
+
+int launch_pw_rows_dgrad(hipStream_t st, const ConvArgs& a) {
+  const int col_tiles = a.Ncol / PWR_BN, items = cdiv(a.M, PWR_BM) * col_tiles;
+  // ring slots per middle width (what 160 KB hold next to the row block); FRX_PWR_RING (tuning aid, read per launch)
+  int ring = a.Kc == 256 ? 3 : 4;
+  if (const char* e = getenv("FRX_PWR_RING")) ring = atoi(e);
+  const unsigned lds = pw_rows_lds(a.Kc, a.Ncol, ring);
+  FRX_CHECK_ARG(ring >= 2 && ring <= 4 && lds <= 159u * 1024u, "pw_rows: %d ring slots, %u bytes of LDS", ring, lds);
+  const bool add = a.addend != nullptr;
+  note_igemm_launch(PWR_BM, PWR_BN, 8, 64, ring, MODE_DGRAD, 2, EPI_BNBWD_OUT, add, 1, 2);
+#define FRX_PWR3(K_, R_) do { if (add) launch_one<K_, true, R_>(st, a, items, col_tiles, lds); else launch_one<K_, false, R_>(st, a, items, col_tiles, lds); } while (0)
+#define FRX_PWR(K_) do { if (ring == 2) FRX_PWR3(K_, 2); else if (ring == 3) FRX_PWR3(K_, 3); else FRX_PWR3(K_, 4); } while (0)
+  if (a.Kc == 64) FRX_PWR(64);
+  else if (a.Kc == 128) FRX_PWR(128);
+  else FRX_PWR(256);
+#undef FRX_PWR
+#undef FRX_PWR3
+  FRX_LAUNCH_CHECK();
+  return FRX_OK;
+}
+
+}  // namespace frx
+
+FRX_DBG_EXPORT(frx_debug_times_pw_rows)

@@ -854,13 +854,6 @@ class ResNet50Engine:
         of the gradient buffer the next step accumulates into (model_utils.py:184-187)."""
         if getattr(self, "_prep_table", None) is None:
             self._build_prep_table()
-        if os.environ.get("FRX_AB_SGD", "1") == "0":       # (A/B aid of round 4: the three launches the fused one replaced)
-            ops.sgd_step(self.params, self.grads, self.mom, 0.0 if lr is None else lr, momentum, weight_decay, grad_scale,
-                         lr_dev=self.lr_dev if lr is None else None)
-            self.sync_weights(pad=False)
-            if zero_grads:
-                self.zero_grad()
-            return
         ops.sgd_step_prep(self.dtype, self._prep_table, self._sgd_blocks, self.params, self.grads, self.mom,
                           0.0 if lr is None else lr, momentum, weight_decay, grad_scale,
                           lr_dev=self.lr_dev if lr is None else None, zero_grads=zero_grads)

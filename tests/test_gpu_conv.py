@@ -1,6 +1,8 @@
 """GPU parity of the implicit-GEMM convolution kernels (forward with fused BN+ReLU prologue and
 statistics epilogue, dgrad, wgrad, stem) through the C ABI against ATen CPU fp32 -- the oracle at
 the backbone boundary (torchvision itself is absent: parity unpinned upstream)."""
+import ctypes
+
 import numpy as np
 import pytest
 import torch
@@ -536,6 +538,57 @@ def test_dgrad_compact_stride2_addend(monkeypatch, dtype, shape, tile):
     out = torch.empty_like(ref)
     ops.conv_dgrad_bn(d, dz, wt, out, addend=compact, pro_y=y, pro_coef=coef, addend_stride=2)
     assert torch.equal(out, ref)
+
+
+@pytest.mark.parametrize("case", [(256, 64, 28, 6, 1), (512, 128, 14, 9, 1), (1024, 256, 7, 21, 1), (2048, 512, 4, 37, 1),
+                                  (256, 128, 28, 5, 2), (512, 256, 14, 7, 2), (1024, 512, 7, 13, 2), (1024, 256, 7, 5, 0)],
+                         ids=lambda c: f"{c[0]}x{c[1]}h{c[2]}n{c[3]}add{c[4]}")
+def test_row_resident_conv1_input_gradient_equals_the_tiled_kernel(monkeypatch, case):
+    """csrc/pw_rows.hip (the conv1-type input gradient with a row block's BN-backward operand resident in LDS, LDS-DMA
+    prefetched epilogue operands, statistics closed as invstd * (sum dz*y - mean * sum dz)) against k_igemm on the same
+    call (FRX_PW_ROWS=0): the gradient and the kept dy bit for bit, the totals to fp32 rounding.  Ragged pixel counts
+    (M % 64 != 0), the compact stride-2 addend of a block's first conv1, no addend, coefficients from totals or given."""
+    from frx import ops
+    Ci, Co, Hi, N, addk = case
+    dtype, R = 1, 8
+    d = ops.conv_desc(dtype, N, Hi, Hi, Ci, Co, 1, 1, 1, 0)
+    T = ops.TORCH_DT[dtype]
+    g = torch.Generator().manual_seed(Ci + Hi)
+    dz, y = _mk(dtype, N, Hi, Hi, Co, seed=1).to(DEV), _mk(dtype, N, Hi, Hi, Co, seed=2).to(DEV) + 0.3
+    wt = _mk(dtype, Ci, 1, 1, Co, scale=Co ** -0.5, seed=4).to(DEV)
+    count = N * Hi * Hi
+    tb = torch.zeros(R, 2, Co, device=DEV)
+    tb[:, 0] = (torch.randn(R, Co, generator=g) * 3).to(DEV); tb[:, 1] = (torch.randn(R, Co, generator=g) * 3).to(DEV)
+    gamma = (torch.rand(Co, generator=g) + 0.5).to(DEV)
+    mean, invstd = (torch.randn(Co, generator=g) * 0.2).to(DEV), (torch.rand(Co, generator=g) + 0.5).to(DEV)
+    coef = torch.zeros(3 * Co, device=DEV)
+    ops.bn_bwd_finalize(tb, R, Co, count, gamma, mean, invstd, None, None, coef)
+    ey = _mk(dtype, N, Hi, Hi, Ci, seed=7).to(DEV) + 0.5
+    emu, eis = (torch.randn(Ci, generator=g) * 0.2 + 0.5).to(DEV), (torch.rand(Ci, generator=g) + 0.5).to(DEV)
+    eout = torch.relu(_mk(dtype, N, Hi, Hi, Ci, seed=8)).to(DEV)
+    bits = ((eout.float() > 0).view(-1, 8).to(torch.int32) << torch.arange(8, device=DEV, dtype=torch.int32)).sum(1).to(torch.uint8)
+    Hc = (Hi + 1) // 2
+    add = None if addk == 0 else (_mk(dtype, N, Hi, Hi, Ci, seed=6) if addk == 1 else _mk(dtype, N, Hc, Hc, Ci, seed=6)).to(DEV)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("FRX_PW_ROWS", mode)
+        for given in (False, True):
+            dx = torch.full((N, Hi, Hi, Ci), float("nan"), dtype=T, device=DEV)
+            side = torch.full_like(dz, float("nan"))
+            tout = torch.zeros(R, 2, Ci, device=DEV)
+            kw = dict(pro_coef=coef) if given else dict(pro_tot=ops.bn_tot(tb, R, count, gamma, mean=mean, invstd=invstd))
+            ops.conv_dgrad_bn(d, dz, wt, dx, addend=add, pro_y=y, epi_y=ey, epi_out_bits=bits, epi_mean=emu, epi_invstd=eis,
+                              epi_totals=tout, epi_replicas=R, pro_dy_out=side, addend_stride=2 if addk == 2 else 0, **kw)
+            f = (ctypes.c_int * 12)()
+            ops._lib.lib().frx_last_conv_launch(f)
+            assert f[10] == (2 if mode == "1" and Co <= 256 else 0), "which kernel ran (middle widths up to 256 take the row-resident one)"
+            res[mode, given] = (dx, side, tout.sum(0))
+    for given in (False, True):
+        (dx0, s0, t0), (dx1, s1, t1) = res["0", given], res["1", given]
+        assert torch.isfinite(dx1.float()).all() and torch.isfinite(s1.float()).all()
+        assert torch.equal(dx1, dx0) and torch.equal(s1, s0)
+        assert (t1 - t0).abs().max().item() <= 1e-4 * t0.abs().max().item(), (t1 - t0).abs().max().item() / t0.abs().max().item()
+    assert torch.equal(res["1", False][0], res["1", True][0])
 
 
 @pytest.mark.parametrize("dtype", [0, 1], ids=["f32", "bf16"])
