@@ -22,9 +22,12 @@
 namespace frx {
 
 constexpr int PWR_BM = 64, PWR_BN = 128, PWR_NT = 512;
-constexpr int PWR_EBYTES = 2 * 4 * 4 * 1024;       // one ring slot of epilogue operands: [tensor (addend, raw y)][row fragment][wave] x 1 KiB (lane-linear)
+// one ring slot of epilogue operands: [tensor (addend, raw y)][row fragment][wave] x 1 KiB (lane-linear 16-byte pieces), then
+// the merge-ReLU mask bytes as [row fragment][wave] x 256 B (lane-linear dwords: the dword that holds the lane's byte)
+constexpr int PWR_EBYTES = 2 * 4 * 4 * 1024 + 4 * 4 * 256;
+constexpr int PWR_LUT = 256 * 16;                  // mask byte -> 16-byte AND mask over 8 packed bf16
 
-unsigned pw_rows_lds(int Kc, int Ncol, int ring) { return (unsigned)(PWR_BM * Kc * 2 + ring * PWR_EBYTES + 3 * Kc * 4 + 2 * Ncol * 4); }
+unsigned pw_rows_lds(int Kc, int Ncol, int ring) { return (unsigned)(PWR_BM * Kc * 2 + ring * PWR_EBYTES + PWR_LUT + 3 * Kc * 4 + 2 * Ncol * 4); }
 
 // (hipcc may park a block-uniform descriptor in vector registers when scalar registers run short; the DMA wants it in SGPRs)
 __device__ __forceinline__ u32x4_t pwr_sgpr4(u32x4_t r) {
@@ -33,14 +36,20 @@ __device__ __forceinline__ u32x4_t pwr_sgpr4(u32x4_t r) {
   for (int i = 0; i < 4; ++i) o[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)r[i]);
   return o;
 }
+// LDS-DMA of one dword per lane (lane-linear at M0 + 4 * lane), as dma16
+__device__ __forceinline__ void dma4(u32x4_t rsrc, unsigned lds_addr, unsigned voff, int soff) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dword %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff) : "memory");
+}
 
-// XOR swizzle of the 16-byte slot index of a [64 rows][RB bytes] image read with ds_read_b128 in the MFMA fragment pattern
-// (row = lane & 15, slot = 4 ks + (lane >> 4)): the 16 lanes of a service group ({fq 0: fr 0-3, 12-15; fq 1: fr 4-11}, ...)
-// land on 16 distinct 16-byte positions of the 256-byte bank row.
 // The per-item barrier orders LDS traffic only.  __syncthreads() is fence + barrier: its fence drains vmcnt -- the compute
 // waves' output stores and, worse, every DMA a loader has in flight (the ring would be one item deep whatever its size).
 __device__ __forceinline__ void pwr_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// XOR swizzle of the 16-byte slot index of a [64 rows][RB bytes] image read with ds_read_b128 in the MFMA fragment pattern
+// (row = lane & 15, slot = 4 ks + (lane >> 4)): the 16 lanes of a service group ({fq 0: fr 0-3, 12-15; fq 1: fr 4-11}, ...)
+// land on 16 distinct 16-byte positions of the 256-byte bank row.
 template <int RB> __device__ __forceinline__ int pwr_swz(int row) {
   if constexpr (RB >= 256) return row & 15;
   else return (row >> 1) & 7;
@@ -48,25 +57,33 @@ template <int RB> __device__ __forceinline__ int pwr_swz(int row) {
 
 // One block per CU, eight waves: waves 0-3 compute (wave w: all 64 pixels x columns 32 w .. 32 w + 31 of the item's 128),
 // waves 4-7 only LOAD -- wave 4 + w keeps RING - 1 items of wave w's epilogue operands in flight by LDS-DMA, lane for lane
-// the 16-byte pieces lane l of wave w will consume (the lane-linear image needs no layout).  A loader's instruction stream
-// holds nothing but those DMAs, so its counted vmcnt is exact; one barrier per item hands a filled slot to the compute
-// waves and the slot they just finished back to the loaders.
-template <int KCH, bool ADD, int RING>
+// the 16-byte pieces (and the mask dword) lane l of wave w will consume: the lane-linear image needs no layout.  A loader's
+// instruction stream holds nothing but those DMAs, so its counted vmcnt is exact; one barrier per item hands a filled slot
+// to the compute waves and the slot they just finished back to the loaders.
+// The compute waves are the bound (measured: the epilogue arithmetic of an item, ~2 us on one wave per SIMD; MFMA 0.2-0.7),
+// so their instruction count is what is tuned: the mask is applied to the PACKED result through a 256-entry LDS table (one
+// AND per bf16 pair), and with CTN > 0 -- the launch has CTN <= 4 column tiles -- the per-channel sums of every column tile
+// stay in registers for the whole block (one lane-reduction per block instead of per item); with two column tiles the
+// weight fragments of both stay in registers as well.
+template <int KCH, bool ADD, int RING, int CTN>
 __global__ __launch_bounds__(PWR_NT, 2) void k_pw_rows_dgrad(ConvArgs a, int items, int col_tiles) {
   typedef bf16_t T;
   constexpr int RB = KCH * 2, SPR = KCH / 8, KS = KCH / 32;
   constexpr int CT = 256;                               // compute threads
   constexpr int ALD = KS, RSTEP = CT / SPR;             // 16-byte loads per compute thread, tensor and row block; rows between them
-  constexpr int NE = ADD ? 8 : 4;                       // DMA instructions per item and loader wave
+  constexpr int NE = (ADD ? 8 : 4) + 4;                 // DMA instructions per item and loader wave
   constexpr bool APF = KCH <= 128;                      // the next row block's raw operand rows are requested an item ahead (registers)
+  constexpr bool WRES = CTN == 2;                       // both column tiles' weight fragments resident in registers
+  constexpr int NCT = CTN > 0 ? CTN : 1;
   constexpr unsigned OOB = 0x80000000u;
   static_assert(KCH == 64 || KCH == 128 || KCH == 256, "middle widths served");
-  static_assert(RING >= 2 && RING <= 5, "ring slots");
+  static_assert(RING >= 2 && RING <= 5 && (CTN == 0 || CTN == 2), "ring slots; column tiles held in registers");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sA = smem;
   char* sE = sA + PWR_BM * RB;
-  float* sTab = reinterpret_cast<float*>(sE + RING * PWR_EBYTES);  // [KCH / 8][alpha, beta, gam][8]
-  float* sStat = sTab + 3 * KCH;                                  // [2][Ncol]: sum dz, sum dz * y
+  char* sLut = sE + RING * PWR_EBYTES;
+  float* sTab = reinterpret_cast<float*>(sLut + PWR_LUT);         // [KCH / 8][alpha, beta, gam][8]
+  float* sStat = sTab + 3 * KCH;                                  // CTN == 0: [2][Ncol]: sum dz, sum dz * y
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool loader = wave >= 4;
   const int cw = wave & 3;                              // the compute wave (whose operands a loader fetches)
@@ -77,12 +94,15 @@ __global__ __launch_bounds__(PWR_NT, 2) void k_pw_rows_dgrad(ConvArgs a, int ite
 
   const unsigned ybytes = (unsigned)a.M * (unsigned)a.Ncol * 2u;
   const int Hc = (a.Ho + 1) >> 1, Wc = (a.Wo + 1) >> 1, hw = a.Ho * a.Wo;
+  const unsigned rstep = 16u * (unsigned)a.Ncol * 2u;   // bytes between the lane's row fragments
+  // byte offsets of the lane's four 16-byte pieces of item (m0, n0) in the output-shaped tensors (yo) and in the addend (ao)
   auto row_offsets = [&](int m0, int n0, unsigned (&yo)[4], unsigned (&ao)[4]) {
     const int nb = n0 + 32 * cw + 8 * fq;
+    const unsigned y0 = (unsigned)(((m0 + fr) * a.Ncol + nb) * 2);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int m = m0 + 16 * i + fr;
-      yo[i] = m < a.M ? (unsigned)((m * a.Ncol + nb) * 2) : OOB;
+      yo[i] = m < a.M ? y0 + (unsigned)i * rstep : OOB;
       ao[i] = yo[i];
       if (ADD && a.add_stride == 2) {
         const int n = m / hw, rem = m - n * hw, h = rem / a.Wo, ww = rem - h * a.Wo;
@@ -97,7 +117,9 @@ __global__ __launch_bounds__(PWR_NT, 2) void k_pw_rows_dgrad(ConvArgs a, int ite
     unsigned addbytes = ybytes;
     if (ADD && a.add_stride == 2) addbytes = (unsigned)a.N * Hc * Wc * a.Ncol * 2u;
     const u32x4_t rawEy = pwr_sgpr4(raw_rsrc(a.e_y, ybytes)), rawAdd = pwr_sgpr4(raw_rsrc(ADD ? a.addend : a.e_y, addbytes));
+    const u32x4_t rawBits = pwr_sgpr4(raw_rsrc(a.e_bits, ybytes / 16u));
     const unsigned ldsE = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)sE + (unsigned)cw * 1024u;
+    const unsigned ldsB = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)sE + 32768u + (unsigned)cw * 256u;
     auto issue_dma = [&](int it) {
       const int rb = it / col_tiles, ct = it - rb * col_tiles;
       const unsigned slot = (unsigned)__builtin_amdgcn_readfirstlane((it - lo) % RING) * (unsigned)PWR_EBYTES;
@@ -108,6 +130,9 @@ __global__ __launch_bounds__(PWR_NT, 2) void k_pw_rows_dgrad(ConvArgs a, int ite
         if constexpr (ADD) dma16(rawAdd, ldsE + slot + (unsigned)((0 * 4 + i) * 4096), ao[i], 0);
         dma16(rawEy, ldsE + slot + (unsigned)((1 * 4 + i) * 4096), yo[i], 0);
       }
+      // mask bytes: byte (m * Ncol + nb) / 8 of the lane's piece sits in the dword the four fq-lanes of its row share
+#pragma unroll
+      for (int i = 0; i < 4; ++i) dma4(rawBits, ldsB + slot + (unsigned)(i * 1024), yo[i] == OOB ? OOB : ((yo[i] >> 4) & ~3u), 0);
     };
 #pragma unroll
     for (int k = 0; k < RING - 1; ++k)
@@ -130,7 +155,6 @@ __global__ __launch_bounds__(PWR_NT, 2) void k_pw_rows_dgrad(ConvArgs a, int ite
     const __amdgpu_buffer_rsrc_t rsrcDy = __builtin_amdgcn_make_buffer_rsrc(a.dy_out ? a.dy_out : const_cast<void*>(a.X), 0, a.dy_out ? a.xbytes : 0u, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, a.wbytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(a.Y, 0, ybytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsrcBits = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned char*>(a.e_bits), 0, ybytes / 16u, 0x00020000);
     // a row block's transformed operand -> LDS (thread: one 16-byte channel group `s`, rows row0 + RSTEP * i)
     const int s = tid % SPR, row0 = tid / SPR;
     const float* tab = sTab + s * 24;
@@ -155,33 +179,34 @@ __global__ __launch_bounds__(PWR_NT, 2) void k_pw_rows_dgrad(ConvArgs a, int ite
         *reinterpret_cast<uint4*>(sA + row * RB + ((s ^ pwr_swz<RB>(row)) << 4)) = v;
       }
     };
-    uint4 w[KS][2];
-    unsigned nbits[4];
+    uint4 w[WRES ? 2 : 1][KS][2];
     unsigned wvoff[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) wvoff[j] = (unsigned)(((32 * wave + chan_of(j, fr)) * KCH + 8 * fq) * 2);
-    auto issue_bits = [&](int it) {
-      const int rb = it / col_tiles, ct = it - rb * col_tiles;
-      unsigned yo[4], ao[4];
-      row_offsets(rb * PWR_BM, ct * PWR_BN, yo, ao);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) nbits[i] = __builtin_amdgcn_raw_buffer_load_b8(rsrcBits, yo[i] == OOB ? OOB : (yo[i] >> 4), 0, 0);
-    };
-    auto issue_w = [&](int it) {
-      const int ct = it % col_tiles;
+    auto issue_w = [&](int ct, auto c_tag) {
+      constexpr int C = decltype(c_tag)::value;
       const int sw = ct * PWR_BN * KCH * 2;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) w[ks][j] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rsrcW, wvoff[j], sw + ks * 64, 0));
+        for (int j = 0; j < 2; ++j) w[C][ks][j] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rsrcW, wvoff[j], sw + ks * 64, 0));
     };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
 
-    // set-up: the first row block, weights and mask bytes are requested before the tables are built
+    // set-up: the first row block and the weights are requested before the tables are built
     int cur_rb = lo / col_tiles;
     issue_rows(cur_rb * PWR_BM);
-    issue_w(lo);
-    issue_bits(lo);
-    for (int c = tid; c < 2 * a.Ncol; c += CT) sStat[c] = 0.f;
+    if constexpr (WRES) { issue_w(0, I0{}); issue_w(1, I1{}); }
+    else issue_w(lo % col_tiles, I0{});
+    if constexpr (CTN == 0) { for (int c = tid; c < 2 * a.Ncol; c += CT) sStat[c] = 0.f; }
+    {   // mask table: entry b, dword q = all-ones halves for bits 2q, 2q + 1 of b
+      uint4 m;
+      unsigned* mw = reinterpret_cast<unsigned*>(&m);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) mw[q] = (((unsigned)tid >> (2 * q)) & 1u ? 0xffffu : 0u) | (((unsigned)tid >> (2 * q + 1)) & 1u ? 0xffff0000u : 0u);
+      *reinterpret_cast<uint4*>(sLut + tid * 16) = m;
+    }
     if (a.in_scale) {
       for (int c = tid; c < KCH; c += CT) {
         float* t = sTab + (c >> 3) * 24 + (c & 7);
@@ -201,11 +226,20 @@ __global__ __launch_bounds__(PWR_NT, 2) void k_pw_rows_dgrad(ConvArgs a, int ite
     __syncthreads();
     FRX_STAMP(1);
     bool rows_pending = false;
+    float csum[NCT][8], csq[NCT][8];        // CTN > 0: the block's running sums per column tile; CTN == 0: one item's
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { csum[c][e] = 0.f; csq[c][e] = 0.f; }
 
-    for (int it = lo; it < hi; ++it) {
-      const int rb = it / col_tiles, ct = it - rb * col_tiles;
+    // c_tag: the item's column tile where it indexes registers (CTN > 0), else 0
+    auto do_item = [&](int it, int rb, int ct, auto c_tag) {
+      constexpr int C = decltype(c_tag)::value;
+      constexpr int WC = WRES ? C : 0;
       const int m0 = rb * PWR_BM, n0 = ct * PWR_BN;
-      const char* sEi = sE + ((it - lo) % RING) * PWR_EBYTES + (wave * 1024 + lane * 16);
+      const char* sEs = sE + ((it - lo) % RING) * PWR_EBYTES;
+      const char* sEi = sEs + (wave * 1024 + lane * 16);
+      const char* sBi = sEs + 32768 + (wave * 256 + lane * 4);
       pwr_barrier();                      // item `it`'s operands are in its slot; every compute wave is done with item it - 1
       if (rb != cur_rb) {                 // (block-uniform) the next row block's operand replaces this one
         if (!rows_pending) issue_rows(m0);
@@ -234,18 +268,16 @@ __global__ __launch_bounds__(PWR_NT, 2) void k_pw_rows_dgrad(ConvArgs a, int ite
         for (int i = 0; i < 4; ++i)
 #pragma unroll
           for (int j = 0; j < 2; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w[ks][j]), *reinterpret_cast<bf16x8*>(&fa[i]), acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w[WC][ks][j]), *reinterpret_cast<bf16x8*>(&fa[i]), acc[i][j], 0, 0, 0);
       }
-      unsigned bits[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) bits[i] = nbits[i];
-      if (it + 1 < hi) { issue_w(it + 1); issue_bits(it + 1); }
+      if constexpr (!WRES) { if (it + 1 < hi) issue_w((it + 1) % col_tiles, I0{}); }
 
       unsigned yo[4], ao[4];
       row_offsets(m0, n0, yo, ao);
-      float csum[8], csq[8];
+      if constexpr (CTN == 0) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) { csum[e] = 0.f; csq[e] = 0.f; }
+        for (int e = 0; e < 8; ++e) { csum[0][e] = 0.f; csq[0][e] = 0.f; }
+      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float v[8], yv[8];
@@ -263,34 +295,63 @@ __global__ __launch_bounds__(PWR_NT, 2) void k_pw_rows_dgrad(ConvArgs a, int ite
 #pragma unroll
           for (int e = 0; e < 4; ++e) { yv[2 * e] = __uint_as_float(q[e] << 16); yv[2 * e + 1] = __uint_as_float(q[e] & 0xffff0000u); }
         }
+        const unsigned mb = (*reinterpret_cast<const unsigned*>(sBi + i * 1024) >> (8 * fq)) & 255u;
+        const uint4 mk = *reinterpret_cast<const uint4*>(sLut + mb * 16);
         bf16x8 t;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          v[e] = ((bits[i] >> e) & 1u) ? v[e] : 0.f;
-          t[e] = (bf16_t)v[e];
-          v[e] = (float)t[e];                                   // statistics of what the next kernel reads
-        }
-        __builtin_amdgcn_raw_buffer_store_b128(*reinterpret_cast<u32x4_t*>(&t), rsrcY, yo[i], 0, 0);
+        for (int e = 0; e < 8; ++e) t[e] = (bf16_t)v[e];
+        u32x4_t tw = *reinterpret_cast<u32x4_t*>(&t);
+        tw[0] &= mk.x; tw[1] &= mk.y; tw[2] &= mk.z; tw[3] &= mk.w;      // the mask on the packed result: +0.0 where the merge output was <= 0
+        __builtin_amdgcn_raw_buffer_store_b128(tw, rsrcY, yo[i], 0, 0);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { csum[e] += v[e]; csq[e] += v[e] * yv[e]; }
+        for (int e = 0; e < 4; ++e) {                            // statistics of what the next kernel reads
+          const float vl = __uint_as_float(tw[e] << 16), vh = __uint_as_float(tw[e] & 0xffff0000u);
+          csum[C][2 * e] += vl; csum[C][2 * e + 1] += vh;
+          csq[C][2 * e] += vl * yv[2 * e]; csq[C][2 * e + 1] += vh * yv[2 * e + 1];
+        }
       }
-      lane16_butterfly<8, 8>(csum, csq, fr);
-      if (fr < 8) {                       // lane (fq, fr < 8) owns column 32 wave + 8 fq + fr of every column tile: no other lane of the block adds to it
-        const int col = n0 + 32 * wave + 8 * fq + fr;
-        sStat[col] += csum[0];
-        sStat[a.Ncol + col] += csq[0];
+      if constexpr (CTN == 0) {
+        lane16_butterfly<8, 8>(csum[0], csq[0], fr);
+        if (fr < 8) {                       // lane (fq, fr < 8) owns column 32 wave + 8 fq + fr of every column tile: no other lane of the block adds to it
+          const int col = n0 + 32 * wave + 8 * fq + fr;
+          sStat[col] += csum[0][0];
+          sStat[a.Ncol + col] += csq[0][0];
+        }
       }
+    };
+    for (int it = lo; it < hi; ++it) {
+      const int rb = it / col_tiles, ct = it - rb * col_tiles;
+      if constexpr (CTN == 0) do_item(it, rb, ct, I0{});
+      else { if (ct == 0) do_item(it, rb, ct, I0{}); else do_item(it, rb, ct, I1{}); }
     }
     FRX_STAMP(2);
+    if constexpr (CTN > 0) {              // the block's sums: one lane-reduction per column tile, then straight into the replicated totals
+      const int rep = blockIdx.x & (a.stat_R - 1);
+#pragma unroll
+      for (int c = 0; c < NCT; ++c) {
+        lane16_butterfly<8, 8>(csum[c], csq[c], fr);
+        if (fr < 8) {
+          const int col = c * PWR_BN + 32 * wave + 8 * fq + fr;
+          const float s1 = csum[c][0], s2 = csq[c][0];
+          if (s1 != 0.f || s2 != 0.f) {
+            __hip_atomic_fetch_add(a.stat_tot + ((long)rep * 2 + 0) * a.Ncol + col, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(a.stat_tot + ((long)rep * 2 + 1) * a.Ncol + col, a.e_invstd[col] * (s2 - a.e_mean[col] * s1), __ATOMIC_RELAXED,
+                                   __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+      }
+    }
   }
-  __syncthreads();
-  const int rep = blockIdx.x & (a.stat_R - 1);
-  for (int c = tid; c < a.Ncol; c += PWR_NT) {
-    const float s1 = sStat[c], s2 = sStat[a.Ncol + c];
-    if (s1 != 0.f || s2 != 0.f) {
-      __hip_atomic_fetch_add(a.stat_tot + ((long)rep * 2 + 0) * a.Ncol + c, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __hip_atomic_fetch_add(a.stat_tot + ((long)rep * 2 + 1) * a.Ncol + c, a.e_invstd[c] * (s2 - a.e_mean[c] * s1), __ATOMIC_RELAXED,
-                             __HIP_MEMORY_SCOPE_AGENT);
+  if constexpr (CTN == 0) {
+    __syncthreads();
+    const int rep = blockIdx.x & (a.stat_R - 1);
+    for (int c = tid; c < a.Ncol; c += PWR_NT) {
+      const float s1 = sStat[c], s2 = sStat[a.Ncol + c];
+      if (s1 != 0.f || s2 != 0.f) {
+        __hip_atomic_fetch_add(a.stat_tot + ((long)rep * 2 + 0) * a.Ncol + c, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(a.stat_tot + ((long)rep * 2 + 1) * a.Ncol + c, a.e_invstd[c] * (s2 - a.e_mean[c] * s1), __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
   }
 #ifdef FRX_DBG_TIMES
@@ -307,32 +368,31 @@ bool pw_rows_dgrad_ok(const ConvArgs& a, int dtype, int epi) {
          (!a.addend || a.add_stride == 2 || a.add_stride == 0 || a.add_stride == 1);
 }
 
-template <int KCH, bool ADD, int RING>
+template <int KCH, bool ADD, int RING, int CTN>
 static void launch_one(hipStream_t st, const ConvArgs& a, int items, int col_tiles, unsigned lds) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw_rows_dgrad<KCH, ADD, RING>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw_rows_dgrad<KCH, ADD, RING, CTN>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     attr_done = true;
   }
   const int grid = items < 256 ? items : 256;
-  hipLaunchKernelGGL((k_pw_rows_dgrad<KCH, ADD, RING>), dim3(grid), dim3(PWR_NT), lds, st, a, items, col_tiles);
+  hipLaunchKernelGGL((k_pw_rows_dgrad<KCH, ADD, RING, CTN>), dim3(grid), dim3(PWR_NT), lds, st, a, items, col_tiles);
 }
 
 int launch_pw_rows_dgrad(hipStream_t st, const ConvArgs& a) {
   const int col_tiles = a.Ncol / PWR_BN, items = cdiv(a.M, PWR_BM) * col_tiles;
-  // ring slots per middle width (what 160 KB hold next to the row block); FRX_PWR_RING (tuning aid, read per launch)
-  int ring = a.Kc == 256 ? 3 : 4;
-  if (const char* e = getenv("FRX_PWR_RING")) ring = atoi(e);
+  constexpr int ring = 3;             // (2, 3 and 4 slots measured alike: the compute waves are the bound)
   const unsigned lds = pw_rows_lds(a.Kc, a.Ncol, ring);
-  FRX_CHECK_ARG(ring >= 2 && ring <= 4 && lds <= 159u * 1024u, "pw_rows: %d ring slots, %u bytes of LDS", ring, lds);
+  FRX_CHECK_ARG(lds <= 159u * 1024u, "pw_rows: %u bytes of LDS", lds);
   const bool add = a.addend != nullptr;
+  // statistics and weights of both column tiles in registers: layer1's shape
+  int ctn = (a.Kc == 64 && col_tiles == 2) ? 2 : 0;        // (four tiles, or two at 128 channels, cost more registers than two waves per SIMD have)
+  if (const char* e = getenv("FRX_PWR_CTN")) { if (atoi(e) == 0) ctn = 0; }      // (tuning aid, read per launch)
   note_igemm_launch(PWR_BM, PWR_BN, 8, 64, ring, MODE_DGRAD, 2, EPI_BNBWD_OUT, add, 1, 2);
-#define FRX_PWR3(K_, R_) do { if (add) launch_one<K_, true, R_>(st, a, items, col_tiles, lds); else launch_one<K_, false, R_>(st, a, items, col_tiles, lds); } while (0)
-#define FRX_PWR(K_) do { if (ring == 2) FRX_PWR3(K_, 2); else if (ring == 3) FRX_PWR3(K_, 3); else FRX_PWR3(K_, 4); } while (0)
-  if (a.Kc == 64) FRX_PWR(64);
-  else if (a.Kc == 128) FRX_PWR(128);
-  else FRX_PWR(256);
-#undef FRX_PWR
+#define FRX_PWR3(K_, C_) do { if (add) launch_one<K_, true, ring, C_>(st, a, items, col_tiles, lds); else launch_one<K_, false, ring, C_>(st, a, items, col_tiles, lds); } while (0)
+  if (a.Kc == 64) { if (ctn == 2) FRX_PWR3(64, 2); else FRX_PWR3(64, 0); }
+  else if (a.Kc == 128) FRX_PWR3(128, 0);
+  else FRX_PWR3(256, 0);
 #undef FRX_PWR3
   FRX_LAUNCH_CHECK();
   return FRX_OK;
