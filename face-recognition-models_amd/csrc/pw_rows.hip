@@ -360,8 +360,233 @@ __global__ __launch_bounds__(PWR_NT, 2) void k_pw_rows_dgrad(ConvArgs a, int ite
 #endif
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The conv3-type FORWARD of a bottleneck block (1x1, middle width -> 4x: torchvision Bottleneck.conv3 behind bn2 + ReLU,
+// backbones.py:16-18), same organisation without loaders -- its epilogue reads nothing: a row block's normalised input
+// relu(scale * x + shift) is built once and stays in LDS, the block walks its (row block, column tile) items, the weights come
+// from L2 straight into fragment registers (resident when the launch has two column tiles), the output is stored as bf16 and
+// the BatchNorm statistics (sum, sum of squares of the rounded output) go to the replicated totals -- per column tile in
+// registers for the whole block where the launch has two tiles, else through the per-item lane reduction and an LDS table.
+// Four waves per block, several blocks per CU (the LDS footprint is the row block).
+template <int KCH, int CTN>
+__global__ __launch_bounds__(256, KCH <= 128 ? 3 : 2) void k_pw_rows_fwd(ConvArgs a, int items, int col_tiles) {
+  typedef bf16_t T;
+  constexpr int RB = KCH * 2, SPR = KCH / 8, KS = KCH / 32;
+  constexpr int CT = 256;
+  constexpr int ALD = KS, RSTEP = CT / SPR;
+  constexpr bool APF = KCH <= 128;
+  constexpr bool WRES = CTN == 2;
+  constexpr int NCT = CTN > 0 ? CTN : 1;
+  constexpr unsigned OOB = 0x80000000u;
+  static_assert(KCH == 64 || KCH == 128 || KCH == 256, "middle widths served");
+  static_assert(CTN == 0 || CTN == 2, "column tiles held in registers");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* sA = smem;
+  float* sTab = reinterpret_cast<float*>(sA + PWR_BM * RB);       // [KCH / 8][scale, shift][8]
+  float* sStat = sTab + 2 * KCH;                                  // CTN == 0: [2][Ncol]
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int fr = lane & 15, fq = lane >> 4;
+  const int lo = (int)((long)items * blockIdx.x / gridDim.x), hi = (int)((long)items * (blockIdx.x + 1) / gridDim.x);
+  if (lo >= hi) return;
+  FRX_STAMP(0);
+  const unsigned ybytes = (unsigned)a.M * (unsigned)a.Ncol * 2u;
+  const unsigned rstep = 16u * (unsigned)a.Ncol * 2u;
+  const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.X), 0, a.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, a.wbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcY = __builtin_amdgcn_make_buffer_rsrc(a.Y, 0, ybytes, 0x00020000);
+  const int s = tid % SPR, row0 = tid / SPR;
+  const float* tab = sTab + s * 16;
+  uint4 rx[ALD];
+  auto issue_rows = [&](int m0) {
+#pragma unroll
+    for (int i = 0; i < ALD; ++i) {
+      const int m = m0 + row0 + RSTEP * i;
+      rx[i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rsrcX, m < a.M ? (unsigned)((m * KCH + s * 8) * 2) : OOB, 0, 0));
+    }
+  };
+  auto commit_rows = [&](int m0) {
+#pragma unroll
+    for (int i = 0; i < ALD; ++i) {
+      const int row = row0 + RSTEP * i, m = m0 + row;
+      uint4 v = bn_relu_vec<T>(rx[i], tab, tab + 8, a.in_relu);
+      if (m >= a.M) v = make_uint4(0, 0, 0, 0);          // (rows past M load as 0, which the prologue turns into f(0))
+      *reinterpret_cast<uint4*>(sA + row * RB + ((s ^ pwr_swz<RB>(row)) << 4)) = v;
+    }
+  };
+  uint4 w[WRES ? 2 : 1][KS][2];
+  unsigned wvoff[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) wvoff[j] = (unsigned)(((32 * wave + chan_of(j, fr)) * KCH + 8 * fq) * 2);
+  auto issue_w = [&](int ct, auto c_tag) {
+    constexpr int C = decltype(c_tag)::value;
+    const int sw = ct * PWR_BN * KCH * 2;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) w[C][ks][j] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rsrcW, wvoff[j], sw + ks * 64, 0));
+  };
+  using I0 = std::integral_constant<int, 0>;
+  using I1 = std::integral_constant<int, 1>;
+
+  int cur_rb = lo / col_tiles;
+  issue_rows(cur_rb * PWR_BM);
+  if constexpr (WRES) { issue_w(0, I0{}); issue_w(1, I1{}); }
+  else issue_w(lo % col_tiles, I0{});
+  if constexpr (CTN == 0) { for (int c = tid; c < 2 * a.Ncol; c += CT) sStat[c] = 0.f; }
+  if (a.in_scale) {
+    for (int c = tid; c < KCH; c += CT) {
+      float* t = sTab + (c >> 3) * 16 + (c & 7);
+      t[0] = a.in_scale[c]; t[8] = a.in_shift[c];
+    }
+  } else {                                // the producer's replicated totals -> scale / shift (bn_tot.h)
+    const BnTot b = bn_tot_copy(a.in_tot);
+    bn_tot_foreach<CT>(b.tot, b.R, KCH, [&](int c, double sm, double sq) {
+      float mean, invstd, sc, sh; double var;
+      bn_fwd_consts(sm, sq, b.inv_count, b.gamma[c], b.beta[c], b.eps, mean, invstd, sc, sh, var);
+      float* t = sTab + (c >> 3) * 16 + (c & 7);
+      t[0] = sc; t[8] = sh;
+    });
+  }
+  __syncthreads();
+  commit_rows(cur_rb * PWR_BM);
+  pwr_barrier();
+  FRX_STAMP(1);
+  bool rows_pending = false;
+  float csum[NCT][8], csq[NCT][8];
+#pragma unroll
+  for (int c = 0; c < NCT; ++c)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { csum[c][e] = 0.f; csq[c][e] = 0.f; }
+
+  auto do_item = [&](int it, int rb, int ct, auto c_tag) {
+    constexpr int C = decltype(c_tag)::value;
+    constexpr int WC = WRES ? C : 0;
+    const int m0 = rb * PWR_BM, n0 = ct * PWR_BN;
+    if (rb != cur_rb) {                 // (block-uniform) the next row block's operand replaces this one
+      if (!rows_pending) issue_rows(m0);
+      pwr_barrier();                    // every wave is done reading the old one
+      commit_rows(m0);
+      pwr_barrier();
+      cur_rb = rb; rows_pending = false;
+    }
+    if constexpr (APF) {
+      if (ct == col_tiles - 1 && it + 1 < hi) { issue_rows(m0 + PWR_BM); rows_pending = true; }
+    }
+    f32x4 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      uint4 fa[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = 16 * i + fr;
+        fa[i] = *reinterpret_cast<const uint4*>(sA + row * RB + (((ks * 4 + fq) ^ pwr_swz<RB>(row)) << 4));
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w[WC][ks][j]), *reinterpret_cast<bf16x8*>(&fa[i]), acc[i][j], 0, 0, 0);
+    }
+    if constexpr (!WRES) { if (it + 1 < hi) issue_w((it + 1) % col_tiles, I0{}); }
+    const unsigned y0 = (unsigned)(((m0 + fr) * a.Ncol + n0 + 32 * wave + 8 * fq) * 2);
+    if constexpr (CTN == 0) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { csum[0][e] = 0.f; csq[0][e] = 0.f; }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      bf16x8 t;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) t[e] = (bf16_t)acc[i][e >> 2][e & 3];
+      u32x4_t tw = *reinterpret_cast<u32x4_t*>(&t);
+      __builtin_amdgcn_raw_buffer_store_b128(tw, rsrcY, m0 + 16 * i + fr < a.M ? y0 + (unsigned)i * rstep : OOB, 0, 0);
+      if (m0 + 16 * i + fr >= a.M) { tw[0] = 0u; tw[1] = 0u; tw[2] = 0u; tw[3] = 0u; }      // (rows past M are exactly 0 anyway: zero operand rows)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {                              // statistics of what the next kernel reads
+        const float vl = __uint_as_float(tw[e] << 16), vh = __uint_as_float(tw[e] & 0xffff0000u);
+        csum[C][2 * e] += vl; csum[C][2 * e + 1] += vh;
+        csq[C][2 * e] += vl * vl; csq[C][2 * e + 1] += vh * vh;
+      }
+    }
+    if constexpr (CTN == 0) {
+      lane16_butterfly<8, 8>(csum[0], csq[0], fr);
+      if (fr < 8) {
+        const int col = n0 + 32 * wave + 8 * fq + fr;
+        sStat[col] += csum[0][0];
+        sStat[a.Ncol + col] += csq[0][0];
+      }
+    }
+  };
+  for (int it = lo; it < hi; ++it) {
+    const int rb = it / col_tiles, ct = it - rb * col_tiles;
+    if constexpr (CTN == 0) do_item(it, rb, ct, I0{});
+    else { if (ct == 0) do_item(it, rb, ct, I0{}); else do_item(it, rb, ct, I1{}); }
+  }
+  FRX_STAMP(2);
+  const int rep = blockIdx.x & (a.stat_R - 1);
+  if constexpr (CTN > 0) {
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+      lane16_butterfly<8, 8>(csum[c], csq[c], fr);
+      if (fr < 8) {
+        const int col = c * PWR_BN + 32 * wave + 8 * fq + fr;
+        __hip_atomic_fetch_add(a.stat_tot + ((long)rep * 2 + 0) * a.Ncol + col, csum[c][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(a.stat_tot + ((long)rep * 2 + 1) * a.Ncol + col, csq[c][0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  } else {
+    __syncthreads();
+    for (int c = tid; c < a.Ncol; c += CT) {
+      const float s1 = sStat[c], s2 = sStat[a.Ncol + c];
+      if (s1 != 0.f || s2 != 0.f) {
+        __hip_atomic_fetch_add(a.stat_tot + ((long)rep * 2 + 0) * a.Ncol + c, s1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_fetch_add(a.stat_tot + ((long)rep * 2 + 1) * a.Ncol + c, s2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+#ifdef FRX_DBG_TIMES
+  __builtin_amdgcn_s_waitcnt(0);
+  FRX_STAMP(3);
+#endif
+}
+
+bool pw_rows_fwd_ok(const ConvArgs& a, int dtype, int epi) {
+  if (const char* e = getenv("FRX_PW_ROWS")) { if (!(atoi(e) & 2)) return false; }
+  const bool pw = a.mode == MODE_FWD && a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0;
+  return dtype == FRX_BF16 && pw && (a.in_scale || a.in_tot.tot) && epi == EPI_STATS && a.stat_tot && !a.stat_partial && !a.out_f32 && !a.bias &&
+         !a.dy_out && !a.addend && (a.Kc == 64 || a.Kc == 128 || (a.Kc == 256 && getenv("FRX_PWR_FWD256"))) && a.Ncol % PWR_BN == 0 && a.Ncol >= 2 * a.Kc;
+}
+
+template <int KCH, int CTN>
+static void launch_fwd_one(hipStream_t st, const ConvArgs& a, int items, int col_tiles, unsigned lds) {
+  static bool attr_done = false;
+  if (!attr_done) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw_rows_fwd<KCH, CTN>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    attr_done = true;
+  }
+  const int cap = 256 * (KCH <= 128 ? 3 : 2), grid = items < cap ? items : cap;
+  hipLaunchKernelGGL((k_pw_rows_fwd<KCH, CTN>), dim3(grid), dim3(256), lds, st, a, items, col_tiles);
+}
+
+int launch_pw_rows_fwd(hipStream_t st, const ConvArgs& a) {
+  const int col_tiles = a.Ncol / PWR_BN, items = cdiv(a.M, PWR_BM) * col_tiles;
+  const unsigned lds = (unsigned)(PWR_BM * a.Kc * 2 + 2 * a.Kc * 4 + 2 * a.Ncol * 4);
+  int ctn = (a.Kc == 64 && col_tiles == 2) ? 2 : 0;
+  if (const char* e = getenv("FRX_PWR_CTN")) { if (atoi(e) == 0) ctn = 0; }      // (tuning aid, read per launch)
+  note_igemm_launch(PWR_BM, PWR_BN, 4, 64, 0, MODE_FWD, 1, EPI_STATS, 0, 1, 2);
+  if (a.Kc == 64) { if (ctn == 2) launch_fwd_one<64, 2>(st, a, items, col_tiles, lds); else launch_fwd_one<64, 0>(st, a, items, col_tiles, lds); }
+  else if (a.Kc == 128) launch_fwd_one<128, 0>(st, a, items, col_tiles, lds);
+  else launch_fwd_one<256, 0>(st, a, items, col_tiles, lds);
+  FRX_LAUNCH_CHECK();
+  return FRX_OK;
+}
+
 bool pw_rows_dgrad_ok(const ConvArgs& a, int dtype, int epi) {
-  if (const char* e = getenv("FRX_PW_ROWS")) { if (atoi(e) == 0) return false; }
+  if (const char* e = getenv("FRX_PW_ROWS")) { if (!(atoi(e) & 1)) return false; }      // (bit 0: input gradients, bit 1: forwards)
   const bool pw = a.mode == MODE_DGRAD && a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0 && !a.s2c;
   return dtype == FRX_BF16 && pw && a.X2 && epi == EPI_BNBWD_OUT && a.e_bits && a.stat_tot && !a.stat_partial && !a.out_f32 &&
          (a.Kc == 64 || a.Kc == 128 || a.Kc == 256) && a.Ncol % PWR_BN == 0 && a.Ncol >= 2 * a.Kc &&

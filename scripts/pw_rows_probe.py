@@ -32,7 +32,7 @@ for (Ci, Co, Hi) in [(256, 64, 28), (512, 128, 14), (1024, 256, 7)]:
     res = []
     cfgs = [None] + (sys.argv[1:] or [""])
     for cfg in cfgs:
-        os.environ["FRX_PW_ROWS"] = "0" if cfg is None else "1"
+        os.environ["FRX_PW_ROWS"] = "0" if cfg is None else "3"
         if cfg: os.environ["FRX_PWR_RING"] = cfg
         else: os.environ.pop("FRX_PWR_RING", None)
         try:
@@ -59,3 +59,23 @@ for (Ci, Co, Hi) in [(256, 64, 28), (512, 128, 14), (1024, 256, 7)]:
         per = t / (items / nb)
         line += f" | per item (compute wave 0, us): barrier wait {np.median(per[:,0]):5.2f} row-block switch {np.median(per[:,1]):5.2f} mfma {np.median(per[:,2]):5.2f} epilogue {np.median(per[:,3]):5.2f}"
     print(line, flush=True)
+    # the conv3-type forward of the same block: Co -> Ci here (middle width -> block width)
+    df = ops.conv_desc(ops.BF16, N, Hi, Hi, Co, Ci, 1, 1, 1, 0)
+    xin = torch.randn(N, Hi, Hi, Co, device=DEV).bfloat16(); wf = (torch.randn(Ci, 1, 1, Co, device=DEV) * Co ** -0.5).bfloat16()
+    sc = torch.rand(Co, device=DEV) + 0.5; sh = torch.randn(Co, device=DEV) * 0.1
+    tin = torch.zeros(R, 2, Co, device=DEV); tin[0, 0] = 1.0; tin[0, 1] = float(M)
+    gam = torch.rand(Co, device=DEV) + 0.5; bet = torch.randn(Co, device=DEV) * 0.1
+    yout = torch.empty(N, Hi, Hi, Ci, device=DEV, dtype=torch.bfloat16); tf = torch.zeros(R, 2, Ci, device=DEV)
+    bnin = ops.bn_tot(tin, R, M, gam, beta=bet)
+    ffn = lambda: ops.conv_fwd_tot(df, xin, wf, yout, in_bn=bnin, in_relu=True, stat_totals=tf, stat_replicas=R)
+    r = []
+    for mode in ("0", "3"):
+        os.environ["FRX_PW_ROWS"] = mode
+        warm = timeit(ffn); cold = []
+        for _ in range(5):
+            flush.fill_(1); torch.cuda.synchronize()
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record(); ffn(); e1.record(); torch.cuda.synchronize()
+            cold.append(e0.elapsed_time(e1) * 1e3)
+        r.append((warm, float(np.median(cold))))
+    print(f"fwd   {Co}->{Ci} H{Hi}: k_igemm {r[0][0]:6.1f} us warm {r[0][1]:6.1f} cold | rows {r[1][0]:6.1f} warm {r[1][1]:6.1f} cold", flush=True)

@@ -591,6 +591,46 @@ def test_row_resident_conv1_input_gradient_equals_the_tiled_kernel(monkeypatch, 
     assert torch.equal(res["1", False][0], res["1", True][0])
 
 
+@pytest.mark.parametrize("case", [(64, 256, 28, 6), (128, 512, 14, 9), (256, 1024, 7, 21), (64, 512, 9, 5), (128, 256, 14, 3)],
+                         ids=lambda c: f"{c[0]}x{c[1]}h{c[2]}n{c[3]}")
+def test_row_resident_conv3_forward_equals_the_tiled_kernel(monkeypatch, case):
+    """csrc/pw_rows.hip, forward flavour (the conv3-type 1x1 behind bn2 + ReLU, statistics into replicated totals) against
+    k_igemm on the same call (FRX_PW_ROWS=0): the output bit for bit, the totals to fp32 summation order.  Ragged pixel
+    counts; two, four and eight column tiles (two: weights and statistics held in registers)."""
+    from frx import ops
+    Ci, Co, Hi, N = case
+    dtype, R = 1, 8
+    d = ops.conv_desc(dtype, N, Hi, Hi, Ci, Co, 1, 1, 1, 0)
+    T = ops.TORCH_DT[dtype]
+    g = torch.Generator().manual_seed(Ci + Hi)
+    x = _mk(dtype, N, Hi, Hi, Ci, seed=1).to(DEV) + 0.2
+    w = _mk(dtype, Co, 1, 1, Ci, scale=Ci ** -0.5, seed=4).to(DEV)
+    count = N * Hi * Hi
+    xf = x.float().view(-1, Ci)
+    tin = torch.zeros(R, 2, Ci, device=DEV)
+    tin[0, 0] = xf.sum(0); tin[0, 1] = (xf * xf).sum(0)
+    tin[1:, 0] = (torch.randn(R - 1, Ci, generator=g) * 0.01).to(DEV); tin[0, 0] -= tin[1:, 0].sum(0)
+    gamma, beta = (torch.rand(Ci, generator=g) + 0.5).to(DEV), (torch.randn(Ci, generator=g) * 0.2).to(DEV)
+    res = {}
+    monkeypatch.setenv("FRX_PWR_FWD256", "1")       # (the 256-channel instantiation is built but not the default: slower than k_igemm)
+    for mode in ("0", "3"):
+        monkeypatch.setenv("FRX_PW_ROWS", mode)
+        y = torch.full((N, Hi, Hi, Co), float("nan"), dtype=T, device=DEV)
+        tout = torch.zeros(R, 2, Co, device=DEV)
+        ops.conv_fwd_tot(d, x, w, y, in_bn=ops.bn_tot(tin, R, count, gamma, beta=beta), in_relu=True, stat_totals=tout, stat_replicas=R)
+        f = (ctypes.c_int * 12)()
+        ops._lib.lib().frx_last_conv_launch(f)
+        assert f[10] == (2 if mode == "3" else 0), "which kernel ran"
+        res[mode] = (y, tout.sum(0))
+    (y0, t0), (y1, t1) = res["0"], res["3"]
+    assert torch.isfinite(y1.float()).all()
+    assert torch.equal(y1, y0)
+    assert (t1 - t0).abs().max().item() <= 2e-5 * t0.abs().max().item(), (t1 - t0).abs().max().item() / t0.abs().max().item()
+    yf = y1.float().view(-1, Co)
+    ref = torch.stack([yf.sum(0), (yf * yf).sum(0)])
+    assert (t1 - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
+
+
 @pytest.mark.parametrize("dtype", [0, 1], ids=["f32", "bf16"])
 def test_grouped_wgrad_matches_per_layer(dtype):
     """frx_wgrad_group_*: one persistent launch over a work list == the per-layer frx_conv_wgrad / frx_conv_wgrad_bn
