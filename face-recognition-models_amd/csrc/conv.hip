@@ -151,6 +151,7 @@ static int launch_igemm(hipStream_t st, ConvArgs a, int dtype) {
   if (a.mode == MODE_STEM) return launch_igemm_stem(st, a, dtype, c, grid, epi);
   if (pw_rows_dgrad_ok(a, dtype, epi)) return launch_pw_rows_dgrad(st, a);
   if (pw_rows_fwd_ok(a, dtype, epi)) return launch_pw_rows_fwd(st, a);
+  if (pw_stream_ok(a, dtype, epi)) return launch_pw_stream(st, a);
   if (a.mode == MODE_DGRAD)
     return a.X2 ? launch_igemm_dgrad_bn(st, a, dtype, c, grid, epi, a.addend != nullptr)
                 : launch_igemm_dgrad_plain(st, a, dtype, c, grid, epi, a.addend != nullptr);

@@ -76,6 +76,10 @@ int launch_pw_rows_dgrad(hipStream_t st, const ConvArgs& a);
 bool pw_rows_fwd_ok(const ConvArgs& a, int dtype, int epi);       // conv3-type forwards (BN + ReLU prologue, statistics into totals), bf16
 int launch_pw_rows_fwd(hipStream_t st, const ConvArgs& a);
 
+// streamed pointwise kernels (pw_stream.hip): conv1-type forwards / conv3-type input gradients of layer1 and layer2, bf16
+bool pw_stream_ok(const ConvArgs& a, int dtype, int epi);
+int launch_pw_stream(hipStream_t st, const ConvArgs& a);
+
 // patch-mode 3x3 (k_igemm MODE_FWD3 / MODE_DGRAD3: bf16, stride 1, pad 1; 128 x bn tile on 2 x 2 waves, or 64 x 128 on 1 x 4)
 int launch_igemm_p3(hipStream_t st, const ConvArgs& a, int epi, int bm, int bn);
 

@@ -42,6 +42,8 @@ def igemm_class(dtype_name, f):
     derives from the kernel symbol): tile, gather mode, prologue, epilogue, staging"""
     bm, bn, waves, kc, ns, mode, pro, epi, add, persist, spec = f[:11]
     stage = "patch" if mode in (3, 4) else (f"dma{ns}" if ns else "ring")
+    if spec == 3:       # csrc/pw_stream.hip: a wave streams 16 pixels at a time, operand fragments straight from global memory, weights in LDS
+        return f"k_pw_stream<{dtype_name},16x{bn}x{waves}w,{_MODE[mode]},pro={_PRO[pro]},epi={_EPI[epi]},stream>"
     if spec == 2:       # csrc/pw_rows.hip: a row block's operand resident in LDS, persistent blocks over (row block, column tile) items
         return f"k_pw_rows<{dtype_name},{bm}x{bn}x{waves}w,{_MODE[mode]},pro={_PRO[pro]},epi={_EPI[epi]}{'+add' if add else ''},rows>"
     return (f"k_igemm<{dtype_name},{bm}x{bn}x{waves}w,kc{kc},{_MODE[mode]},pro={_PRO[pro]},epi={_EPI[epi]}{'+add' if add else ''},"

@@ -631,6 +631,75 @@ def test_row_resident_conv3_forward_equals_the_tiled_kernel(monkeypatch, case):
     assert (t1 - ref).abs().max().item() <= 1e-4 * ref.abs().max().item()
 
 
+@pytest.mark.parametrize("case", [(256, 64, 28, 6), (512, 128, 14, 9), (256, 128, 28, 3), (256, 64, 9, 300)], ids=lambda c: f"{c[0]}x{c[1]}h{c[2]}n{c[3]}")
+def test_streamed_conv1_forward_equals_the_tiled_kernel(monkeypatch, case):
+    """csrc/pw_stream.hip, forward flavour (a block's conv1 on its stored input: operand fragments straight from global memory,
+    weights resident in LDS, statistics into replicated totals) against k_igemm on the same call (FRX_PW_STREAM=0)."""
+    from frx import ops
+    Ci, Co, Hi, N = case
+    dtype, R = 1, 8
+    d = ops.conv_desc(dtype, N, Hi, Hi, Ci, Co, 1, 1, 1, 0)
+    T = ops.TORCH_DT[dtype]
+    x = _mk(dtype, N, Hi, Hi, Ci, seed=1).to(DEV)
+    w = _mk(dtype, Co, 1, 1, Ci, scale=Ci ** -0.5, seed=4).to(DEV)
+    res = {}
+    for mode in ("0", "2"):         # (2: every instantiated shape, also the layer2 ones the default leaves to k_igemm)
+        monkeypatch.setenv("FRX_PW_STREAM", mode)
+        y = torch.full((N, Hi, Hi, Co), float("nan"), dtype=T, device=DEV)
+        tout = torch.zeros(R, 2, Co, device=DEV)
+        ops.conv_fwd_tot(d, x, w, y, in_bn=None, stat_totals=tout, stat_replicas=R)
+        f = (ctypes.c_int * 12)()
+        ops._lib.lib().frx_last_conv_launch(f)
+        assert f[10] == (3 if mode == "2" else 0), "which kernel ran"
+        res[mode] = (y, tout.sum(0))
+    (y0, t0), (y1, t1) = res["0"], res["2"]
+    assert torch.isfinite(y1.float()).all() and torch.equal(y1, y0)
+    assert (t1 - t0).abs().max().item() <= 2e-5 * t0.abs().max().item(), (t1 - t0).abs().max().item() / t0.abs().max().item()
+
+
+@pytest.mark.parametrize("case", [(64, 256, 28, 6), (128, 512, 14, 9), (64, 256, 9, 300)], ids=lambda c: f"{c[0]}x{c[1]}h{c[2]}n{c[3]}")
+def test_streamed_conv3_input_gradient_equals_the_tiled_kernel(monkeypatch, case):
+    """csrc/pw_stream.hip, input-gradient flavour (conv3 of layer1 / layer2: the BN-backward operand of two full-width tensors
+    built in registers, mask and statistics of bn2 behind it) against k_igemm on the same call: gradient bit for bit, totals to
+    fp32 rounding (sum dz * xhat is closed as invstd * (sum dz * y - mean * sum dz)).  Coefficients from totals or given."""
+    from frx import ops
+    Ci, Co, Hi, N = case
+    dtype, R = 1, 8
+    d = ops.conv_desc(dtype, N, Hi, Hi, Ci, Co, 1, 1, 1, 0)
+    T = ops.TORCH_DT[dtype]
+    g = torch.Generator().manual_seed(Ci + Hi)
+    dz, y = _mk(dtype, N, Hi, Hi, Co, seed=1).to(DEV), _mk(dtype, N, Hi, Hi, Co, seed=2).to(DEV) + 0.3
+    wt = _mk(dtype, Ci, 1, 1, Co, scale=Co ** -0.5, seed=4).to(DEV)
+    count = N * Hi * Hi
+    tb = torch.zeros(R, 2, Co, device=DEV)
+    tb[:, 0] = (torch.randn(R, Co, generator=g) * 3).to(DEV); tb[:, 1] = (torch.randn(R, Co, generator=g) * 3).to(DEV)
+    gamma = (torch.rand(Co, generator=g) + 0.5).to(DEV)
+    mean, invstd = (torch.randn(Co, generator=g) * 0.2).to(DEV), (torch.rand(Co, generator=g) + 0.5).to(DEV)
+    coef = torch.zeros(3 * Co, device=DEV)
+    ops.bn_bwd_finalize(tb, R, Co, count, gamma, mean, invstd, None, None, coef)
+    ey = _mk(dtype, N, Hi, Hi, Ci, seed=7).to(DEV) + 0.5
+    esc = (torch.rand(Ci, generator=g) + 0.5).to(DEV); esc[::4] *= -1
+    esh = (torch.randn(Ci, generator=g) * 0.3).to(DEV)
+    emu, eis = (torch.randn(Ci, generator=g) * 0.2 + 0.5).to(DEV), (torch.rand(Ci, generator=g) + 0.5).to(DEV)
+    res = {}
+    for mode in ("0", "2"):
+        monkeypatch.setenv("FRX_PW_STREAM", mode)
+        for given in (False, True):
+            dx = torch.full((N, Hi, Hi, Ci), float("nan"), dtype=T, device=DEV)
+            tout = torch.zeros(R, 2, Ci, device=DEV)
+            kw = dict(pro_coef=coef) if given else dict(pro_tot=ops.bn_tot(tb, R, count, gamma, mean=mean, invstd=invstd))
+            ops.conv_dgrad_bn(d, dz, wt, dx, pro_y=y, epi_y=ey, epi_scale=esc, epi_shift=esh, epi_mean=emu, epi_invstd=eis,
+                              epi_totals=tout, epi_replicas=R, **kw)
+            f = (ctypes.c_int * 12)()
+            ops._lib.lib().frx_last_conv_launch(f)
+            assert f[10] == (3 if mode == "2" else 0), "which kernel ran"
+            res[mode, given] = (dx, tout.sum(0))
+    for given in (False, True):
+        (dx0, t0), (dx1, t1) = res["0", given], res["2", given]
+        assert torch.isfinite(dx1.float()).all() and torch.equal(dx1, dx0)
+        assert (t1 - t0).abs().max().item() <= 1e-4 * t0.abs().max().item(), (t1 - t0).abs().max().item() / t0.abs().max().item()
+
+
 @pytest.mark.parametrize("dtype", [0, 1], ids=["f32", "bf16"])
 def test_grouped_wgrad_matches_per_layer(dtype):
     """frx_wgrad_group_*: one persistent launch over a work list == the per-layer frx_conv_wgrad / frx_conv_wgrad_bn
