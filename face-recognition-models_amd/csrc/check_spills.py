@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Build-time check: the patch-mode k_igemm kernels (MODE_FWD3 / MODE_DGRAD3) count their own
+"""Build-time check: the patch-mode k_igemm kernels (MODE_FWD3 / MODE_DGRAD3) and k_pw_rows_dgrad's loader waves count their own
 `s_waitcnt vmcnt(N)` over inline-asm LDS-DMA that hipcc does not model.  A compiler-inserted scratch spill is a
 vector-memory operation too: it would shift those counts.  So every such kernel must have no scratch at all:
 private_segment_fixed_size == 0 and vgpr_spill_count == 0 in the code object's metadata.  Fails the build otherwise.
@@ -34,6 +34,11 @@ def kernels(obj):
     return out
 
 
+def counts_vmcnt(name):
+    """kernels that wait on hand-counted vmcnt: the patch-mode k_igemm and the loader waves of k_pw_rows_dgrad"""
+    return is_patch_mode(name) or "k_pw_rows_dgrad" in name
+
+
 def is_patch_mode(name):
     # k_igemm<T, BM, BN, WM, WN, MODE, ...>: MODE is the fifth integer template argument (3 = MODE_FWD3, 4 = MODE_DGRAD3)
     m = re.match(r"_ZN3frx7k_igemmI(?:DF16b|f)((?:Li\d+E)+)", name)
@@ -47,7 +52,7 @@ def main(objs):
     bad, seen = [], 0
     for obj in objs:
         for k in kernels(obj):
-            if not is_patch_mode(k["name"]):
+            if not counts_vmcnt(k["name"]):
                 continue
             seen += 1
             if k.get("private_segment_fixed_size", 0) != 0 or k.get("vgpr_spill_count", 0) != 0:
@@ -59,7 +64,7 @@ def main(objs):
         print(f"check_spills: FAILED ({len(bad)} of {seen} patch-mode kernels use scratch)" if seen else
               "check_spills: no patch-mode kernel found (name pattern changed?)", file=sys.stderr)
         return 1
-    print(f"check_spills: {seen} patch-mode kernels, none uses scratch")
+    print(f"check_spills: {seen} kernels with hand-counted vmcnt, none uses scratch")
     return 0
 
 

@@ -15,6 +15,18 @@ def label(name):
         stage = "patch" if mode in (3, 4) else (f"dma{ns}" if ns else "ring")
         return (f"k_igemm<{'bf16' if m.group(1)=='DF16b' else 'f32'},{bm}x{bn}x{wm * wn}w,kc{kc},{MODE[mode]},pro={PRO[pro]},epi={EPI[epi]}"
                 f"{'+add' if add else ''},{stage}{',persist' if persist else ''}{',stagewaves' if spec else ''}>")
+    # the row-resident / streamed pointwise kernels (csrc/pw_rows.hip, pw_stream.hip): mangled or demangled
+    m = re.search(r"k_pw_rows_dgradILi\d+ELb([01])E|k_pw_rows_dgrad<\d+, (true|false)", name)
+    if m:
+        add = (m.group(1) == "1") if m.group(1) is not None else (m.group(2) == "true")
+        return f"k_pw_rows<bf16,64x128x8w,dgrad,pro=bn_bwd,epi=bnbwd_stats_maskout{'+add' if add else ''},rows>"
+    if "k_pw_rows_fwd" in name: return "k_pw_rows<bf16,64x128x4w,fwd,pro=bn_relu,epi=stats,rows>"
+    m = re.search(r"k_pw_streamILi\d+ELi(\d+)ELb([01])E|k_pw_stream<\d+, (\d+), (true|false)", name)
+    if m:
+        n = m.group(1) or m.group(3)
+        dg = (m.group(2) == "1") if m.group(2) is not None else (m.group(4) == "true")
+        return (f"k_pw_stream<bf16,16x{n}x8w,dgrad,pro=bn_bwd,epi=bnbwd_stats,stream>" if dg else
+                f"k_pw_stream<bf16,16x{n}x8w,fwd,pro=none,epi=stats,stream>")
     if "k_wgrad_grouped" in name:          # (both instantiations, mangled or demangled: frx/ops.py labels them as one class)
         return "k_wgrad_grouped<f32>" if re.search(r"k_wgrad_groupedIf|k_wgrad_grouped<float", name) else "k_wgrad_grouped<bf16>"
     m = re.search(r"k_wgradI(DF16b|f)Li(\d+)E", name)
