@@ -61,7 +61,7 @@ def main(objs):
         print(f"check_spills: {k['name']}: scratch {k.get('private_segment_fixed_size')} B, vgpr spills {k.get('vgpr_spill_count')}",
               file=sys.stderr)
     if bad or not seen:
-        print(f"check_spills: FAILED ({len(bad)} of {seen} patch-mode kernels use scratch)" if seen else
+        print(f"check_spills: FAILED ({len(bad)} of {seen} kernels with hand-counted vmcnt use scratch)" if seen else
               "check_spills: no patch-mode kernel found (name pattern changed?)", file=sys.stderr)
         return 1
     print(f"check_spills: {seen} kernels with hand-counted vmcnt, none uses scratch")

@@ -27,7 +27,7 @@ constexpr int PWR_BM = 64, PWR_BN = 128, PWR_NT = 512;
 constexpr int PWR_EBYTES = 2 * 4 * 4 * 1024 + 4 * 4 * 256;
 constexpr int PWR_LUT = 256 * 16;                  // mask byte -> 16-byte AND mask over 8 packed bf16
 
-unsigned pw_rows_lds(int Kc, int Ncol, int ring) { return (unsigned)(PWR_BM * Kc * 2 + ring * PWR_EBYTES + PWR_LUT + 3 * Kc * 4 + 2 * Ncol * 4); }
+unsigned pw_rows_lds(int Kc, int Ncol, int ring, int rbn) { return (unsigned)((rbn ? rbn : 1) * PWR_BM * Kc * 2 + ring * PWR_EBYTES + PWR_LUT + 3 * Kc * 4 + 2 * Ncol * 4); }
 
 // (hipcc may park a block-uniform descriptor in vector registers when scalar registers run short; the DMA wants it in SGPRs)
 __device__ __forceinline__ u32x4_t pwr_sgpr4(u32x4_t r) {
@@ -65,14 +65,20 @@ template <int RB> __device__ __forceinline__ int pwr_swz(int row) {
 // AND per bf16 pair), and with CTN > 0 -- the launch has CTN <= 4 column tiles -- the per-channel sums of every column tile
 // stay in registers for the whole block (one lane-reduction per block instead of per item); with two column tiles the
 // weight fragments of both stay in registers as well.
-template <int KCH, bool ADD, int RING, int CTN>
+// RBN > 0 (layer2 / layer3: four / eight column tiles, a dozen / half a dozen items per block): the block's range spans at
+// most RBN row blocks; ALL of them are built at set-up and stay in LDS, and the items are walked COLUMN TILE MAJOR -- the
+// weight fragments are fetched once per column tile instead of once per item (measured: that fetch, queued behind the
+// loaders' DMAs, cost 0.8-1.3 us of an item's 3.2) and the lane reduction of the statistics runs once per column tile.
+template <int KCH, bool ADD, int RING, int CTN, int RBN>
 __global__ __launch_bounds__(PWR_NT, 2) void k_pw_rows_dgrad(ConvArgs a, int items, int col_tiles) {
+  constexpr bool COLMAJ = RBN > 0;
+  static_assert(!COLMAJ || CTN == 0, "column-tile-major walk: statistics per column tile, weights per column tile");
   typedef bf16_t T;
   constexpr int RB = KCH * 2, SPR = KCH / 8, KS = KCH / 32;
   constexpr int CT = 256;                               // compute threads
   constexpr int ALD = KS, RSTEP = CT / SPR;             // 16-byte loads per compute thread, tensor and row block; rows between them
   constexpr int NE = (ADD ? 8 : 4) + 4;                 // DMA instructions per item and loader wave
-  constexpr bool APF = KCH <= 128;                      // the next row block's raw operand rows are requested an item ahead (registers)
+  constexpr bool APF = KCH <= 128 && !COLMAJ;           // the next row block's raw operand rows are requested an item ahead (registers)
   constexpr bool WRES = CTN == 2;                       // both column tiles' weight fragments resident in registers
   constexpr int NCT = CTN > 0 ? CTN : 1;
   constexpr unsigned OOB = 0x80000000u;
@@ -80,7 +86,7 @@ __global__ __launch_bounds__(PWR_NT, 2) void k_pw_rows_dgrad(ConvArgs a, int ite
   static_assert(RING >= 2 && RING <= 5 && (CTN == 0 || CTN == 2), "ring slots; column tiles held in registers");
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* sA = smem;
-  char* sE = sA + PWR_BM * RB;
+  char* sE = sA + (COLMAJ ? RBN : 1) * PWR_BM * RB;
   char* sLut = sE + RING * PWR_EBYTES;
   float* sTab = reinterpret_cast<float*>(sLut + PWR_LUT);         // [KCH / 8][alpha, beta, gam][8]
   float* sStat = sTab + 3 * KCH;                                  // CTN == 0: [2][Ncol]: sum dz, sum dz * y
@@ -91,6 +97,20 @@ __global__ __launch_bounds__(PWR_NT, 2) void k_pw_rows_dgrad(ConvArgs a, int ite
   const int lo = (int)((long)items * blockIdx.x / gridDim.x), hi = (int)((long)items * (blockIdx.x + 1) / gridDim.x);
   if (lo >= hi) return;
   FRX_STAMP(0);
+  // COLMAJ: the block's items in column-tile-major order over its row blocks rb_lo .. rb_lo + nrb - 1; (ct, r) is the walk's
+  // state, the call returns the next item of the range (or -1).  Loaders and compute waves run the same walk.
+  const int rb_lo = lo / col_tiles, nrb = (hi - 1) / col_tiles - rb_lo + 1;
+  auto walk = [&](int& ct, int& r) -> int {
+    while (ct < col_tiles) {
+      while (r < nrb) {
+        const int it = (rb_lo + r) * col_tiles + ct;
+        ++r;
+        if (it >= lo && it < hi) return it;
+      }
+      r = 0; ++ct;
+    }
+    return -1;
+  };
 
   const unsigned ybytes = (unsigned)a.M * (unsigned)a.Ncol * 2u;
   const int Hc = (a.Ho + 1) >> 1, Wc = (a.Wo + 1) >> 1, hw = a.Ho * a.Wo;
@@ -120,9 +140,9 @@ __global__ __launch_bounds__(PWR_NT, 2) void k_pw_rows_dgrad(ConvArgs a, int ite
     const u32x4_t rawBits = pwr_sgpr4(raw_rsrc(a.e_bits, ybytes / 16u));
     const unsigned ldsE = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)sE + (unsigned)cw * 1024u;
     const unsigned ldsB = (unsigned)(unsigned long long)(__attribute__((address_space(3))) char*)sE + 32768u + (unsigned)cw * 256u;
-    auto issue_dma = [&](int it) {
+    auto issue_dma = [&](int it, int seq) {          // seq: the item's position in the block's walk (its ring slot)
       const int rb = it / col_tiles, ct = it - rb * col_tiles;
-      const unsigned slot = (unsigned)__builtin_amdgcn_readfirstlane((it - lo) % RING) * (unsigned)PWR_EBYTES;
+      const unsigned slot = (unsigned)__builtin_amdgcn_readfirstlane(seq % RING) * (unsigned)PWR_EBYTES;
       unsigned yo[4], ao[4];
       row_offsets(rb * PWR_BM, ct * PWR_BN, yo, ao);
 #pragma unroll
@@ -134,19 +154,28 @@ __global__ __launch_bounds__(PWR_NT, 2) void k_pw_rows_dgrad(ConvArgs a, int ite
 #pragma unroll
       for (int i = 0; i < 4; ++i) dma4(rawBits, ldsB + slot + (unsigned)(i * 1024), yo[i] == OOB ? OOB : ((yo[i] >> 4) & ~3u), 0);
     };
+    int lct = 0, lr = 0;              // (COLMAJ) the loaders' position in the walk: RING - 1 items ahead of the compute waves
 #pragma unroll
-    for (int k = 0; k < RING - 1; ++k)
-      if (lo + k < hi) issue_dma(lo + k);
+    for (int k = 0; k < RING - 1; ++k) {
+      if (lo + k < hi) {
+        if constexpr (COLMAJ) issue_dma(walk(lct, lr), k); else issue_dma(lo + k, k);
+      }
+    }
     __syncthreads();                  // (tables built)
-    __syncthreads();                  // (first row block committed)
+    __syncthreads();                  // (first row block / all row blocks committed)
     int cur_rb = lo / col_tiles;
-    for (int it = lo; it < hi; ++it) {
-      // item `it` has landed once at most the DMAs of the items after it are in flight
-      if (it + RING - 2 < hi) wait_vmcnt<(RING - 2) * NE>(); else wait_vmcnt<0>();
-      pwr_barrier();                  // item `it` handed over; the compute waves are done with item it - 1: its slot is free
-      if (it + RING - 1 < hi) issue_dma(it + RING - 1);
-      const int rb = it / col_tiles;
-      if (rb != cur_rb) { pwr_barrier(); cur_rb = rb; }        // (the compute waves' barrier behind a new row block)
+    const int n = hi - lo;
+    for (int k = 0; k < n; ++k) {
+      // item k of the walk has landed once at most the DMAs of the items after it are in flight
+      if (k + RING - 2 < n) wait_vmcnt<(RING - 2) * NE>(); else wait_vmcnt<0>();
+      pwr_barrier();                  // item k handed over; the compute waves are done with item k - 1: its slot is free
+      if (k + RING - 1 < n) {
+        if constexpr (COLMAJ) issue_dma(walk(lct, lr), k + RING - 1); else issue_dma(lo + k + RING - 1, k + RING - 1);
+      }
+      if constexpr (!COLMAJ) {
+        const int rb = (lo + k) / col_tiles;
+        if (rb != cur_rb) { pwr_barrier(); cur_rb = rb; }      // (the compute waves' barrier behind a new row block)
+      }
     }
   } else {
     // ---------------------------------------------------------------- compute waves
@@ -158,25 +187,30 @@ __global__ __launch_bounds__(PWR_NT, 2) void k_pw_rows_dgrad(ConvArgs a, int ite
     // a row block's transformed operand -> LDS (thread: one 16-byte channel group `s`, rows row0 + RSTEP * i)
     const int s = tid % SPR, row0 = tid / SPR;
     const float* tab = sTab + s * 24;
-    uint4 rz[ALD], ry[ALD];
-    auto issue_rows = [&](int m0) {
+    constexpr bool SEQROWS = COLMAJ && KCH == 256;      // (two row blocks of 256 channels in registers at once spill: one after the other)
+    constexpr int NRZ = (COLMAJ && !SEQROWS) ? RBN : 1;
+    uint4 rz[NRZ][ALD], ry[NRZ][ALD];
+    auto issue_rows = [&](int m0, auto z_tag) {
+      constexpr int Z = decltype(z_tag)::value;
 #pragma unroll
       for (int i = 0; i < ALD; ++i) {
         const int m = m0 + row0 + RSTEP * i;
         const unsigned off = m < a.M ? (unsigned)((m * KCH + s * 8) * 2) : OOB;
-        rz[i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rsrcX, off, 0, 0));
-        ry[i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rsrcX2, off, 0, 0));
+        rz[Z][i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rsrcX, off, 0, 0));
+        ry[Z][i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rsrcX2, off, 0, 0));
       }
     };
-    auto commit_rows = [&](int m0) {
+    auto commit_rows = [&](int m0, auto z_tag, int slot) {      // registers of set Z -> row-block image `slot`
+      constexpr int Z = decltype(z_tag)::value;
+      char* sAz = sA + slot * (PWR_BM * RB);
 #pragma unroll
       for (int i = 0; i < ALD; ++i) {
         const int row = row0 + RSTEP * i, m = m0 + row;
-        uint4 v = affine2_vec<T>(rz[i], ry[i], tab, tab + 8, tab + 16);
+        uint4 v = affine2_vec<T>(rz[Z][i], ry[Z][i], tab, tab + 8, tab + 16);
         if (m >= a.M) v = make_uint4(0, 0, 0, 0);          // (rows past M load as 0, which the affine map turns into gam)
         u32x4_t sv; sv[0] = v.x; sv[1] = v.y; sv[2] = v.z; sv[3] = v.w;
         __builtin_amdgcn_raw_buffer_store_b128(sv, rsrcDy, m < a.M ? (unsigned)((m * KCH + s * 8) * 2) : OOB, 0, 0);      // (empty descriptor without dy_out)
-        *reinterpret_cast<uint4*>(sA + row * RB + ((s ^ pwr_swz<RB>(row)) << 4)) = v;
+        *reinterpret_cast<uint4*>(sAz + row * RB + ((s ^ pwr_swz<RB>(row)) << 4)) = v;
       }
     };
     uint4 w[WRES ? 2 : 1][KS][2];
@@ -193,12 +227,19 @@ __global__ __launch_bounds__(PWR_NT, 2) void k_pw_rows_dgrad(ConvArgs a, int ite
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
 
-    // set-up: the first row block and the weights are requested before the tables are built
+    // set-up: the first row block (COLMAJ: every row block of the range) and the weights are requested before the tables are built
     int cur_rb = lo / col_tiles;
-    issue_rows(cur_rb * PWR_BM);
+    int cct = 0, cr = 0;                    // (COLMAJ) the compute waves' position in the walk
+    int nxt = COLMAJ ? walk(cct, cr) : lo;  // the next item
+    issue_rows(cur_rb * PWR_BM, I0{});
+    if constexpr (NRZ > 1) { if (nrb > 1) issue_rows((cur_rb + 1) * PWR_BM, I1{}); }
+    if constexpr (NRZ > 2) { if (nrb > 2) issue_rows((cur_rb + 2) * PWR_BM, I2{}); }
+    if constexpr (NRZ > 3) { if (nrb > 3) issue_rows((cur_rb + 3) * PWR_BM, I3{}); }
     if constexpr (WRES) { issue_w(0, I0{}); issue_w(1, I1{}); }
-    else issue_w(lo % col_tiles, I0{});
+    else issue_w(nxt % col_tiles, I0{});
     if constexpr (CTN == 0) { for (int c = tid; c < 2 * a.Ncol; c += CT) sStat[c] = 0.f; }
     {   // mask table: entry b, dword q = all-ones halves for bits 2q, 2q + 1 of b
       uint4 m;
@@ -222,7 +263,13 @@ __global__ __launch_bounds__(PWR_NT, 2) void k_pw_rows_dgrad(ConvArgs a, int ite
       });
     }
     __syncthreads();
-    commit_rows(cur_rb * PWR_BM);
+    commit_rows(cur_rb * PWR_BM, I0{}, 0);
+    if constexpr (NRZ > 1) { if (nrb > 1) commit_rows((cur_rb + 1) * PWR_BM, I1{}, 1); }
+    if constexpr (NRZ > 2) { if (nrb > 2) commit_rows((cur_rb + 2) * PWR_BM, I2{}, 2); }
+    if constexpr (NRZ > 3) { if (nrb > 3) commit_rows((cur_rb + 3) * PWR_BM, I3{}, 3); }
+    if constexpr (SEQROWS) {
+      for (int r = 1; r < nrb; ++r) { issue_rows((cur_rb + r) * PWR_BM, I0{}); commit_rows((cur_rb + r) * PWR_BM, I0{}, r); }
+    }
     __syncthreads();
     FRX_STAMP(1);
     bool rows_pending = false;
@@ -233,22 +280,47 @@ __global__ __launch_bounds__(PWR_NT, 2) void k_pw_rows_dgrad(ConvArgs a, int ite
       for (int e = 0; e < 8; ++e) { csum[c][e] = 0.f; csq[c][e] = 0.f; }
 
     // c_tag: the item's column tile where it indexes registers (CTN > 0), else 0
-    auto do_item = [&](int it, int rb, int ct, auto c_tag) {
+    // the lane reduction of one column tile's sums into the block's table (CTN == 0)
+    auto flush_stats = [&](int ct) {
+      lane16_butterfly<8, 8>(csum[0], csq[0], fr);
+      if (fr < 8) {                       // lane (fq, fr < 8) owns column 32 wave + 8 fq + fr of every column tile: no other lane of the block adds to it
+        const int col = ct * PWR_BN + 32 * wave + 8 * fq + fr;
+        sStat[col] += csum[0][0];
+        sStat[a.Ncol + col] += csq[0][0];
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { csum[0][e] = 0.f; csq[0][e] = 0.f; }
+    };
+    // seq: the item's position in the walk; nct: the column tile of the NEXT item (-1: none)
+    auto do_item = [&](int it, int seq, int rb, int ct, int nct, auto c_tag) {
       constexpr int C = decltype(c_tag)::value;
       constexpr int WC = WRES ? C : 0;
       const int m0 = rb * PWR_BM, n0 = ct * PWR_BN;
-      const char* sEs = sE + ((it - lo) % RING) * PWR_EBYTES;
+      const char* sAr = sA + (COLMAJ ? (rb - rb_lo) * (PWR_BM * RB) : 0);
+      const char* sEs = sE + (seq % RING) * PWR_EBYTES;
       const char* sEi = sEs + (wave * 1024 + lane * 16);
       const char* sBi = sEs + 32768 + (wave * 256 + lane * 4);
       pwr_barrier();                      // item `it`'s operands are in its slot; every compute wave is done with item it - 1
-      if (rb != cur_rb) {                 // (block-uniform) the next row block's operand replaces this one
-        if (!rows_pending) issue_rows(m0);
-        commit_rows(m0);
-        pwr_barrier();
-        cur_rb = rb; rows_pending = false;
+      if constexpr (!COLMAJ) {
+        if (rb != cur_rb) {               // (block-uniform) the next row block's operand replaces this one
+          if (!rows_pending) issue_rows(m0, I0{});
+          commit_rows(m0, I0{}, 0);
+          pwr_barrier();
+          cur_rb = rb; rows_pending = false;
+        }
       }
       if constexpr (APF) {                // the row block after this one starts with the next item: request its rows now
-        if (ct == col_tiles - 1 && it + 1 < hi) { issue_rows(m0 + PWR_BM); rows_pending = true; }
+        if (ct == col_tiles - 1 && it + 1 < hi) { issue_rows(m0 + PWR_BM, I0{}); rows_pending = true; }
+      }
+      // the item's epilogue operands leave LDS BEFORE the MFMA loop: a lone wave per SIMD has nothing else to cover the ~100
+      // clocks of each LDS read with (12 reads per item ahead of dependent arithmetic were ~40 % of the epilogue's time)
+      uint4 pea[ADD ? 4 : 1], pey[4];
+      unsigned pmb[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        if constexpr (ADD) pea[i] = *reinterpret_cast<const uint4*>(sEi + (0 * 4 + i) * 4096);
+        pey[i] = *reinterpret_cast<const uint4*>(sEi + (1 * 4 + i) * 4096);
+        pmb[i] = *reinterpret_cast<const unsigned*>(sBi + i * 1024);
       }
       f32x4 acc[4][2];
 #pragma unroll
@@ -261,7 +333,7 @@ __global__ __launch_bounds__(PWR_NT, 2) void k_pw_rows_dgrad(ConvArgs a, int ite
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int row = 16 * i + fr;
-          fa[i] = *reinterpret_cast<const uint4*>(sA + row * RB + (((ks * 4 + fq) ^ pwr_swz<RB>(row)) << 4));
+          fa[i] = *reinterpret_cast<const uint4*>(sAr + row * RB + (((ks * 4 + fq) ^ pwr_swz<RB>(row)) << 4));
         }
         // operands swapped (weights first): D[row = channel][col = pixel] -- a lane ends up with 8 consecutive channels of a pixel
 #pragma unroll
@@ -270,33 +342,31 @@ __global__ __launch_bounds__(PWR_NT, 2) void k_pw_rows_dgrad(ConvArgs a, int ite
           for (int j = 0; j < 2; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(*reinterpret_cast<bf16x8*>(&w[WC][ks][j]), *reinterpret_cast<bf16x8*>(&fa[i]), acc[i][j], 0, 0, 0);
       }
-      if constexpr (!WRES) { if (it + 1 < hi) issue_w((it + 1) % col_tiles, I0{}); }
+      if constexpr (!WRES) {              // the next item's weight fragments (COLMAJ: only where the column tile changes)
+        if (nct >= 0 && (!COLMAJ || nct != ct)) issue_w(nct, I0{});
+      }
+      uint4 pmk[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) pmk[i] = *reinterpret_cast<const uint4*>(sLut + ((pmb[i] >> (8 * fq)) & 255u) * 16);
 
       unsigned yo[4], ao[4];
       row_offsets(m0, n0, yo, ao);
-      if constexpr (CTN == 0) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) { csum[0][e] = 0.f; csq[0][e] = 0.f; }
-      }
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         float v[8], yv[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) v[e] = acc[i][e >> 2][e & 3];
         if constexpr (ADD) {
-          const uint4 ea = *reinterpret_cast<const uint4*>(sEi + (0 * 4 + i) * 4096);
-          const unsigned* q = reinterpret_cast<const unsigned*>(&ea);
+          const unsigned* q = reinterpret_cast<const unsigned*>(&pea[i]);
 #pragma unroll
           for (int e = 0; e < 4; ++e) { v[2 * e] += __uint_as_float(q[e] << 16); v[2 * e + 1] += __uint_as_float(q[e] & 0xffff0000u); }
         }
         {
-          const uint4 ey = *reinterpret_cast<const uint4*>(sEi + (1 * 4 + i) * 4096);
-          const unsigned* q = reinterpret_cast<const unsigned*>(&ey);
+          const unsigned* q = reinterpret_cast<const unsigned*>(&pey[i]);
 #pragma unroll
           for (int e = 0; e < 4; ++e) { yv[2 * e] = __uint_as_float(q[e] << 16); yv[2 * e + 1] = __uint_as_float(q[e] & 0xffff0000u); }
         }
-        const unsigned mb = (*reinterpret_cast<const unsigned*>(sBi + i * 1024) >> (8 * fq)) & 255u;
-        const uint4 mk = *reinterpret_cast<const uint4*>(sLut + mb * 16);
+        const uint4 mk = pmk[i];
         bf16x8 t;
 #pragma unroll
         for (int e = 0; e < 8; ++e) t[e] = (bf16_t)v[e];
@@ -310,19 +380,15 @@ __global__ __launch_bounds__(PWR_NT, 2) void k_pw_rows_dgrad(ConvArgs a, int ite
           csq[C][2 * e] += vl * yv[2 * e]; csq[C][2 * e + 1] += vh * yv[2 * e + 1];
         }
       }
-      if constexpr (CTN == 0) {
-        lane16_butterfly<8, 8>(csum[0], csq[0], fr);
-        if (fr < 8) {                       // lane (fq, fr < 8) owns column 32 wave + 8 fq + fr of every column tile: no other lane of the block adds to it
-          const int col = n0 + 32 * wave + 8 * fq + fr;
-          sStat[col] += csum[0][0];
-          sStat[a.Ncol + col] += csq[0][0];
-        }
-      }
+      if constexpr (CTN == 0) { if (nct != ct) flush_stats(ct); }      // (row-major walk: after every item; COLMAJ: once per column tile)
     };
-    for (int it = lo; it < hi; ++it) {
+    for (int seq = 0; nxt >= 0; ++seq) {
+      const int it = nxt;
+      nxt = COLMAJ ? walk(cct, cr) : (it + 1 < hi ? it + 1 : -1);
       const int rb = it / col_tiles, ct = it - rb * col_tiles;
-      if constexpr (CTN == 0) do_item(it, rb, ct, I0{});
-      else { if (ct == 0) do_item(it, rb, ct, I0{}); else do_item(it, rb, ct, I1{}); }
+      const int nct = nxt >= 0 ? nxt % col_tiles : -1;
+      if constexpr (CTN == 0) do_item(it, seq, rb, ct, nct, I0{});
+      else { if (ct == 0) do_item(it, seq, rb, ct, nct, I0{}); else do_item(it, seq, rb, ct, nct, I1{}); }
     }
     FRX_STAMP(2);
     if constexpr (CTN > 0) {              // the block's sums: one lane-reduction per column tile, then straight into the replicated totals
@@ -593,32 +659,39 @@ bool pw_rows_dgrad_ok(const ConvArgs& a, int dtype, int epi) {
          (!a.addend || a.add_stride == 2 || a.add_stride == 0 || a.add_stride == 1);
 }
 
-template <int KCH, bool ADD, int RING, int CTN>
+template <int KCH, bool ADD, int RING, int CTN, int RBN>
 static void launch_one(hipStream_t st, const ConvArgs& a, int items, int col_tiles, unsigned lds) {
   static bool attr_done = false;
   if (!attr_done) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw_rows_dgrad<KCH, ADD, RING, CTN>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw_rows_dgrad<KCH, ADD, RING, CTN, RBN>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
     attr_done = true;
   }
   const int grid = items < 256 ? items : 256;
-  hipLaunchKernelGGL((k_pw_rows_dgrad<KCH, ADD, RING, CTN>), dim3(grid), dim3(PWR_NT), lds, st, a, items, col_tiles);
+  hipLaunchKernelGGL((k_pw_rows_dgrad<KCH, ADD, RING, CTN, RBN>), dim3(grid), dim3(PWR_NT), lds, st, a, items, col_tiles);
 }
 
 int launch_pw_rows_dgrad(hipStream_t st, const ConvArgs& a) {
   const int col_tiles = a.Ncol / PWR_BN, items = cdiv(a.M, PWR_BM) * col_tiles;
-  constexpr int ring = 3;             // (2, 3 and 4 slots measured alike: the compute waves are the bound)
-  const unsigned lds = pw_rows_lds(a.Kc, a.Ncol, ring);
-  FRX_CHECK_ARG(lds <= 159u * 1024u, "pw_rows: %u bytes of LDS", lds);
   const bool add = a.addend != nullptr;
   // statistics and weights of both column tiles in registers: layer1's shape
   int ctn = (a.Kc == 64 && col_tiles == 2) ? 2 : 0;        // (four tiles, or two at 128 channels, cost more registers than two waves per SIMD have)
   if (const char* e = getenv("FRX_PWR_CTN")) { if (atoi(e) == 0) ctn = 0; }      // (tuning aid, read per launch)
+  // column-tile-major walk over resident row blocks where a block's range spans few of them: layer2's shape (128 channels,
+  // four row blocks of 16 KB; stand-alone 48.2 -> 44.4 us).  (256 channels, two row blocks: 38.3 -> 41.5 us -- the second
+  // row block's build at set-up costs more than six items save; not instantiated.)
+  int rbn = a.Kc == 128 ? 4 : 0;
+  const int per_block = cdiv(items, items < 256 ? items : 256);
+  if (ctn || cdiv(col_tiles - 1 + per_block, col_tiles) > rbn) rbn = 0;
+  if (const char* e = getenv("FRX_PWR_COLMAJ")) { if (atoi(e) == 0) rbn = 0; }   // (tuning aid, read per launch)
+  const int ring = rbn ? 2 : 3;       // (2, 3 and 4 slots measured alike: the compute waves are the bound)
+  const unsigned lds = pw_rows_lds(a.Kc, a.Ncol, ring, rbn);
+  FRX_CHECK_ARG(lds <= 159u * 1024u, "pw_rows: %u bytes of LDS", lds);
   note_igemm_launch(PWR_BM, PWR_BN, 8, 64, ring, MODE_DGRAD, 2, EPI_BNBWD_OUT, add, 1, 2);
-#define FRX_PWR3(K_, C_) do { if (add) launch_one<K_, true, ring, C_>(st, a, items, col_tiles, lds); else launch_one<K_, false, ring, C_>(st, a, items, col_tiles, lds); } while (0)
-  if (a.Kc == 64) { if (ctn == 2) FRX_PWR3(64, 2); else FRX_PWR3(64, 0); }
-  else if (a.Kc == 128) FRX_PWR3(128, 0);
-  else FRX_PWR3(256, 0);
-#undef FRX_PWR3
+#define FRX_PWR4(K_, R_, C_, B_) do { if (add) launch_one<K_, true, R_, C_, B_>(st, a, items, col_tiles, lds); else launch_one<K_, false, R_, C_, B_>(st, a, items, col_tiles, lds); } while (0)
+  if (a.Kc == 64) { if (ctn == 2) FRX_PWR4(64, 3, 2, 0); else FRX_PWR4(64, 3, 0, 0); }
+  else if (a.Kc == 128) { if (rbn) FRX_PWR4(128, 2, 0, 4); else FRX_PWR4(128, 3, 0, 0); }
+  else FRX_PWR4(256, 3, 0, 0);
+#undef FRX_PWR4
   FRX_LAUNCH_CHECK();
   return FRX_OK;
 }
