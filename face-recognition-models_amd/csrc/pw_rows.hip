@@ -629,10 +629,12 @@ bool pw_rows_fwd_ok(const ConvArgs& a, int dtype, int epi) {
 
 template <int KCH, int CTN>
 static void launch_fwd_one(hipStream_t st, const ConvArgs& a, int items, int col_tiles, unsigned lds) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[64] = {false};      // (per device: the attribute belongs to the function ON a device)
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!attr_done[dev & 63]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw_rows_fwd<KCH, CTN>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
-    attr_done = true;
+    attr_done[dev & 63] = true;
   }
   const int cap = 256 * (KCH <= 128 ? 3 : 2), grid = items < cap ? items : cap;
   hipLaunchKernelGGL((k_pw_rows_fwd<KCH, CTN>), dim3(grid), dim3(256), lds, st, a, items, col_tiles);
@@ -661,10 +663,12 @@ bool pw_rows_dgrad_ok(const ConvArgs& a, int dtype, int epi) {
 
 template <int KCH, bool ADD, int RING, int CTN, int RBN>
 static void launch_one(hipStream_t st, const ConvArgs& a, int items, int col_tiles, unsigned lds) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[64] = {false};      // (per device: the attribute belongs to the function ON a device)
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!attr_done[dev & 63]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw_rows_dgrad<KCH, ADD, RING, CTN, RBN>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-    attr_done = true;
+    attr_done[dev & 63] = true;
   }
   const int grid = items < 256 ? items : 256;
   hipLaunchKernelGGL((k_pw_rows_dgrad<KCH, ADD, RING, CTN, RBN>), dim3(grid), dim3(PWR_NT), lds, st, a, items, col_tiles);

@@ -229,10 +229,12 @@ bool pw_stream_ok(const ConvArgs& a, int dtype, int epi) {
 
 template <int K, int N, bool DGRAD>
 static void launch_one(hipStream_t st, const ConvArgs& a) {
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[64] = {false};      // (per device: the attribute belongs to the function ON a device)
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (!attr_done[dev & 63]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&k_pw_stream<K, N, DGRAD>), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-    attr_done = true;
+    attr_done[dev & 63] = true;
   }
   const unsigned lds = (unsigned)(N * K * 2 + (DGRAD ? 3 * K * 4 + 2 * N * 4 : 0) + 2 * N * 4);
   const int units = cdiv(a.M, 16);
