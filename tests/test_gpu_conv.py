@@ -541,7 +541,10 @@ def test_dgrad_compact_stride2_addend(monkeypatch, dtype, shape, tile):
 
 
 @pytest.mark.parametrize("case", [(256, 64, 28, 6, 1), (512, 128, 14, 9, 1), (1024, 256, 7, 21, 1), (2048, 512, 4, 37, 1),
-                                  (256, 128, 28, 5, 2), (512, 256, 14, 7, 2), (1024, 512, 7, 13, 2), (1024, 256, 7, 5, 0)],
+                                  (256, 128, 28, 5, 2), (512, 256, 14, 7, 2), (1024, 512, 7, 13, 2), (1024, 256, 7, 5, 0),
+                                  # the bench's own batch: a dozen items per block -- the column-tile-major walk over four resident row
+                                  # blocks (512 <- 128), register-held column tiles over two dozen items (256 <- 64)
+                                  (512, 128, 14, 256, 1), (256, 64, 28, 250, 1)],
                          ids=lambda c: f"{c[0]}x{c[1]}h{c[2]}n{c[3]}add{c[4]}")
 def test_row_resident_conv1_input_gradient_equals_the_tiled_kernel(monkeypatch, case):
     """csrc/pw_rows.hip (the conv1-type input gradient with a row block's BN-backward operand resident in LDS, LDS-DMA
