@@ -78,7 +78,7 @@ __global__ __launch_bounds__(PWR_NT, 2) void k_pw_rows_dgrad(ConvArgs a, int ite
   constexpr int CT = 256;                               // compute threads
   constexpr int ALD = KS, RSTEP = CT / SPR;             // 16-byte loads per compute thread, tensor and row block; rows between them
   constexpr int NE = (ADD ? 8 : 4) + 4;                 // DMA instructions per item and loader wave
-  constexpr bool APF = KCH <= 128 && !COLMAJ;           // the next row block's raw operand rows are requested an item ahead (registers)
+  constexpr bool APF = KCH <= 128 && !COLMAJ && !(KCH == 128 && CTN == 2);      // the next row block's raw operand rows are requested an item ahead (registers; not where both column tiles' weights already fill them)
   constexpr bool WRES = CTN == 2;                       // both column tiles' weight fragments resident in registers
   constexpr int NCT = CTN > 0 ? CTN : 1;
   constexpr unsigned OOB = 0x80000000u;
@@ -678,7 +678,7 @@ int launch_pw_rows_dgrad(hipStream_t st, const ConvArgs& a) {
   const int col_tiles = a.Ncol / PWR_BN, items = cdiv(a.M, PWR_BM) * col_tiles;
   const bool add = a.addend != nullptr;
   // statistics and weights of both column tiles in registers: layer1's shape
-  int ctn = (a.Kc == 64 && col_tiles == 2) ? 2 : 0;        // (four tiles, or two at 128 channels, cost more registers than two waves per SIMD have)
+  int ctn = ((a.Kc == 64 || a.Kc == 128) && col_tiles == 2) ? 2 : 0;      // (four tiles cost more registers than two waves per SIMD have)
   if (const char* e = getenv("FRX_PWR_CTN")) { if (atoi(e) == 0) ctn = 0; }      // (tuning aid, read per launch)
   // column-tile-major walk over resident row blocks where a block's range spans few of them: layer2's shape (128 channels,
   // four row blocks of 16 KB; stand-alone 48.2 -> 44.4 us).  (256 channels, two row blocks: 38.3 -> 41.5 us -- the second
@@ -693,7 +693,7 @@ int launch_pw_rows_dgrad(hipStream_t st, const ConvArgs& a) {
   note_igemm_launch(PWR_BM, PWR_BN, 8, 64, ring, MODE_DGRAD, 2, EPI_BNBWD_OUT, add, 1, 2);
 #define FRX_PWR4(K_, R_, C_, B_) do { if (add) launch_one<K_, true, R_, C_, B_>(st, a, items, col_tiles, lds); else launch_one<K_, false, R_, C_, B_>(st, a, items, col_tiles, lds); } while (0)
   if (a.Kc == 64) { if (ctn == 2) FRX_PWR4(64, 3, 2, 0); else FRX_PWR4(64, 3, 0, 0); }
-  else if (a.Kc == 128) { if (rbn) FRX_PWR4(128, 2, 0, 4); else FRX_PWR4(128, 3, 0, 0); }
+  else if (a.Kc == 128) { if (ctn == 2) FRX_PWR4(128, 3, 2, 0); else if (rbn) FRX_PWR4(128, 2, 0, 4); else FRX_PWR4(128, 3, 0, 0); }
   else FRX_PWR4(256, 3, 0, 0);
 #undef FRX_PWR4
   FRX_LAUNCH_CHECK();
