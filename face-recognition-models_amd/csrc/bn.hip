@@ -211,7 +211,9 @@ __global__ __launch_bounds__(256) void k_merge_fwd(long rows, int C, const T* __
         unsigned bits = 0;
 #pragma unroll
         for (int j = 0; j < V; ++j) {
-          o.set(j, fmaxf(fmaf(a[u].get(j), ks[j], kb[j]) + fmaf(b[u].get(j), ds[j], db[j]), 0.f));
+          // (fma for fma the expression of conv_kernels.h: merge_vec -- a consumer that evaluates the merge in its prologue
+          // (frx_conv_fwd_merge) stages exactly the value this pass writes)
+          o.set(j, fmaxf(fmaf(a[u].get(j), ks[j], fmaf(b[u].get(j), ds[j], kb[j] + db[j])), 0.f));
           bits |= (o.get(j) > 0.f ? 1u : 0u) << j;      // of the ROUNDED output: what `out > 0` would see
         }
         if (rr < rows) {

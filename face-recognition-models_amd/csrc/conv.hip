@@ -106,7 +106,7 @@ static int launch_igemm(hipStream_t st, ConvArgs a, int dtype) {
     // tile per block: the prologue-fed pointwise forwards of layer1/2 gain 7-9 % (the 64->256 conv3: 42.1 -> 38.9 us),
     // the input gradients LOSE 8-15 % -- their epilogues are where the registers run out, and a tile loop without
     // cross-tile prefetch only adds live state there: profiles/r03_persist_layer_times.txt)
-    const bool tile_ok = c.kc == 64 && c.bm == 128 && !c.ns && a.mode == MODE_FWD;
+    const bool tile_ok = c.kc == 64 && c.bm == 128 && !c.ns && a.mode == MODE_FWD && !a.X2;      // (the merge prologue has no persistent instantiation: it spills there)
     if (per_cu > 0 && tile_ok && !a.stat_partial && a.nvb > cap && (cap / 8) % a.tilesN == 0) grid = cap;
   }
   int epi = EPI_PLAIN;
@@ -133,7 +133,7 @@ static int launch_igemm(hipStream_t st, ConvArgs a, int dtype) {
       a.nvb = (int)round_up(a.tilesM, 8) * a.tilesN;
       return launch_igemm_p3(st, a, epi, bm3, bn3);
     }
-    FRX_CHECK_ARG(!(a.dy_out && a.mode == MODE_FWD),
+    FRX_CHECK_ARG(!(a.dy_out && a.mode == MODE_FWD && !a.X2),
                   "conv_fwd_keep: x_norm_out needs the patch-mode launch (partial-statistics rows only where frx_conv_tile's row tile is "
                   "frx_conv_patch_mode's)");
     FRX_CHECK_ARG(!(a.dy_out && (a.R != 1 || a.S != 1)),
@@ -156,6 +156,10 @@ static int launch_igemm(hipStream_t st, ConvArgs a, int dtype) {
     return a.X2 ? launch_igemm_dgrad_bn(st, a, dtype, c, grid, epi, a.addend != nullptr)
                 : launch_igemm_dgrad_plain(st, a, dtype, c, grid, epi, a.addend != nullptr);
   FRX_CHECK_ARG(a.addend == nullptr, "igemm fwd: addend is a dgrad feature");
+  if (a.X2) {      // the merge prologue (frx_conv_fwd_merge)
+    FRX_CHECK_ARG(pointwise, "conv_fwd_merge: a 1x1 / stride 1 convolution");
+    return launch_igemm_fwd(st, a, dtype, c, grid, 3, epi);
+  }
   return launch_igemm_fwd(st, a, dtype, c, grid, (a.in_scale || a.in_tot.tot) ? 1 : 0, epi);
 }
 
@@ -295,6 +299,38 @@ extern "C" int frx_conv_fwd_keep(int device, frx_stream_t stream, const frx_conv
   FRX_CHECK_ARG(!(stat_partial && stat_totals), "conv_fwd_keep: statistics as partial rows OR as totals");
   return conv_fwd_impl(device, stream, d, x, w, in_scale, in_shift, in_relu, nullptr, y, 0, stat_partial, in_bn, stat_totals, stat_replicas,
                        x_norm_out);
+}
+
+// The residual merge of the block BEFORE as the prologue of a 1x1 convolution (replaces that block's frx_block_merge_fwd*
+// launch: torchvision Bottleneck.forward's `out += identity; out = relu(out)` feeding the next Bottleneck's conv1,
+// backbones.py:16-18): x = relu(bn3(y3) + idn') is evaluated while the tiles are staged, stored once (block_out, mask) by the
+// first column of tiles, and never read back by this launch.
+extern "C" int frx_conv_fwd_merge(int device, frx_stream_t stream, const frx_conv_desc* d, const void* y3, const void* idn,
+                                  const void* w, const float* s3, const float* b3, const float* sd, const float* bd,
+                                  const frx_bn_tot* bn3, const frx_bn_tot* bnd, void* block_out, uint8_t* mask, void* y,
+                                  float* stat_partial, float* stat_totals, int stat_replicas) {
+  if (int rc = check_conv(d)) return rc;
+  FRX_CHECK_ARG(!d->stem && d->R == 1 && d->S == 1 && d->stride == 1 && d->pad == 0, "conv_fwd_merge: a 1x1 / stride 1 convolution");
+  FRX_CHECK_ARG(y3 && idn && w && y && block_out, "conv_fwd_merge: NULL pointer");
+  FRX_CHECK_ARG((s3 != nullptr) != (bn3 != nullptr) && (s3 == nullptr) == (b3 == nullptr), "conv_fwd_merge: bn3 as arrays (s3, b3) OR as totals");
+  FRX_CHECK_ARG((sd == nullptr) == (bd == nullptr) && !(sd && bn3) && !(bnd && s3), "conv_fwd_merge: the projection's constants in the same form as bn3's");
+  FRX_CHECK_ARG(!(stat_partial && stat_totals), "conv_fwd_merge: statistics as partial rows OR as totals");
+  FRX_CHECK_ARG(!stat_totals || frx_pow2(stat_replicas), "conv_fwd_merge: stat_replicas must be a power of two");
+  FRX_CHECK_ARG(d->Ci <= 2048, "conv_fwd_merge: up to 2048 input channels (got %d)", d->Ci);
+  for (const frx_bn_tot* t : {bn3, bnd})
+    if (t) FRX_CHECK_ARG(t->totals && t->gamma && t->beta && frx_pow2(t->replicas) && t->count > 0.f,
+                         "conv_fwd_merge: a BatchNorm as totals needs totals / gamma / beta, a power-of-two replica count and count > 0");
+  FRX_ENTER(device);
+  ConvArgs a{};
+  a.X = y3; a.X2 = idn; a.W = w; a.Y = y;
+  a.in_scale = s3; a.in_shift = b3; a.id_scale = sd; a.id_shift = bd; a.in_relu = 1;
+  a.in_tot = bn_tot_arg(bn3); a.id_tot = bn_tot_arg(bnd);
+  a.dy_out = block_out; a.mask_out = mask;
+  a.stat_partial = stat_partial; a.stat_tot = stat_totals; a.stat_R = stat_replicas;
+  a.N = d->N; a.Ho = d->Ho; a.Wo = d->Wo; a.Ncol = d->Co; a.R = 1; a.S = 1; a.stride = 1; a.pad = 0;
+  a.M = d->N * d->Ho * d->Wo;
+  a.mode = MODE_FWD; a.Hx = d->Hi; a.Wx = d->Wi; a.Kc = d->Ci;
+  return launch_igemm((hipStream_t)stream, a, d->dtype);
 }
 
 extern "C" int frx_conv_fwd_tot(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x, const void* w,

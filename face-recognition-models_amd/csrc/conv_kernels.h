@@ -66,7 +66,14 @@ struct ConvArgs {
   // PRO == 2 (dgrad): the gathered operand is the BN backward  alpha*dz + beta*y + gam  of two tensors
   const void* X2;         //   y (raw conv output), same indexing as X (= dz); in_scale = alpha, in_shift = beta
   const float* pro_gam;   //   gam [Kc]
-  void* dy_out;           //   optional (1x1 with PRO == 2; patch mode with any prologue): the transformed operand is also stored here, same indexing as X
+  void* dy_out;           //   optional (1x1 with PRO == 2 / 3; patch mode with any prologue): the transformed operand is also stored here, same indexing as X
+  // PRO == 3 (forward, 1x1): the gathered operand is the residual MERGE of the block before,
+  //   relu(in_scale*X + (id_scale*X2 + (in_shift + id_shift)))  (X = that block's raw conv3 output, X2 = its identity: the block input,
+  //   id_scale = 1 / id_shift = 0, or the raw output of its projection with that BatchNorm's constants) -- what frx_block_merge_fwd
+  //   computes in a pass of its own.  dy_out = the block output (stored by the first column of tiles), mask_out its > 0 bits.
+  const float* id_scale; const float* id_shift;   //   [Kc] or NULL (identity); with in_tot set: derived from id_tot instead
+  BnTot id_tot;           //   the projection's BatchNorm as replicated totals (tot == nullptr: plain identity)
+  unsigned char* mask_out;  //   optional [M * Kc / VEC]: bit j of a byte = channel j of that 16-byte group is > 0
   // epi_bnbwd (dgrad): the output is the gradient w.r.t. a post-BN(-ReLU) activation; mask it, write dz and
   // reduce  sum(dz), sum(dz*xhat)  per channel into stat_partial (what frx_bn_bwd_reduce does in a pass of its own)
   int epi_bnbwd;
@@ -268,6 +275,40 @@ __device__ __forceinline__ uint4 affine2_vec(uint4 rdz, uint4 ry, const float* _
   }
 }
 
+// relu(s3*y + (sd*idn + (b3 + bd))) on a 16-byte vector of each -- k_merge_fwd's expression (bn.hip), fma for fma: the block
+// output a fused consumer stages equals the one the stand-alone merge pass would have written, bit for bit.  It is
+// affine2_vec (the BN-backward prologue's  al*a + (be*b + ga)) followed by the ReLU.  `bits`: the > 0 mask of the ROUNDED
+// result (bit j = element j), the backward's merge-ReLU mask.
+template <typename T>
+__device__ __forceinline__ uint4 merge_vec(uint4 ry, uint4 rid, const float* __restrict__ s3, const float* __restrict__ sd,
+                                           const float* __restrict__ bsum, unsigned& bits) {
+  uint4 v = affine2_vec<T>(ry, rid, s3, sd, bsum);
+  bits = 0;
+  if constexpr (sizeof(T) == 4) {
+    float* o = reinterpret_cast<float*>(&v);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      o[j] = fmaxf(o[j], 0.f);
+      bits |= (o[j] > 0.f ? 1u : 0u) << j;
+    }
+  } else {
+    // packed: a bf16 is negative exactly when its bit pattern is a negative int16 (v_pk_max_i16 against 0 is the ReLU of
+    // two elements; fmaxf never lets a NaN through, so "> 0" is "positive, non-zero int16")
+    typedef short s16x2_t __attribute__((ext_vector_type(2)));
+    unsigned* w = reinterpret_cast<unsigned*>(&v);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      s16x2_t x = *reinterpret_cast<s16x2_t*>(&w[q]);
+      const s16x2_t z = {0, 0};
+      x = __builtin_elementwise_max(x, z);
+      w[q] = *reinterpret_cast<unsigned*>(&x);
+      bits |= ((w[q] & 0xffffu) ? 1u : 0u) << (2 * q);
+      bits |= ((w[q] >> 16) ? 1u : 0u) << (2 * q + 1);
+    }
+  }
+  return v;
+}
+
 template <typename T> __device__ __forceinline__ float load_as_float(const void* p, long i) {
   if constexpr (sizeof(T) == 4) return reinterpret_cast<const float*>(p)[i];
   else return (float)reinterpret_cast<const bf16_t*>(p)[i];
@@ -278,20 +319,21 @@ template <typename T> __device__ __forceinline__ float load_as_float(const void*
 // one barrier per K-chunk, global loads of chunk k+1 in flight under the MFMAs of chunk k.
 // ------------------------------------------------------------------------------------------
 // dynamic LDS bytes of a k_igemm launch: the prologue's per-channel tables (scale, shift[, gam]) over the Kc input channels
-static inline unsigned igemm_pro_lds(int pro, int Kc) { return pro ? (pro == 2 ? 3u : 2u) * (unsigned)Kc * 4u : 0u; }
+static inline unsigned igemm_pro_lds(int pro, int Kc) { return pro ? (pro >= 2 ? 3u : 2u) * (unsigned)Kc * 4u : 0u; }
 
 // MODE (gather geometry) and PRO (BN+ReLU prologue) are compile-time so the steady-state K loop is
 // straight-line code: hipcc then keeps counted s_waitcnt vmcnt(N) for the register ring.
-template <typename T, int BM, int BN, int WM, int WN, int MODE, int PRO, int EPI, bool ADD, int KC = 64, int PD = 3, int NS = 0, bool PERSIST = false, bool SPEC = false>   // PRO: 0 none, 1 BN+ReLU, 2 BN-backward affine; KC: bytes of the contraction axis per row and K-chunk; PD: ring depth; NS > 0: LDS-DMA staging into a ring of NS LDS stages (PRO == 0 only) instead of the register ring
+template <typename T, int BM, int BN, int WM, int WN, int MODE, int PRO, int EPI, bool ADD, int KC = 64, int PD = 3, int NS = 0, bool PERSIST = false, bool SPEC = false>   // PRO: 0 none, 1 BN+ReLU, 2 BN-backward affine, 3 residual merge of the block before (two tensors, 1x1 forward); KC: bytes of the contraction axis per row and K-chunk; PD: ring depth; NS > 0: LDS-DMA staging into a ring of NS LDS stages (PRO == 0 only) instead of the register ring
 // (patch mode: three blocks per CU on the 64-column tile -- except its BN-backward-prologue input gradient, which spilled 13
 // registers at 168 and must not: scratch accesses count in the hand-counted vmcnt; csrc/check_spills.py fails the build on any)
+// (the merge prologue, PRO == 3, on the four-wave tiles: 168 registers without a vector spill -- three blocks per CU)
 // waves per SIMD the register budget must allow: 3 where the kernel fits 168 registers without spilling (measured:
 // +10-20 % on the prologue-free variants), 2 for the BN-prologue variants (they spill 35-50 registers at 3)
 // (WM x WN = 4 waves; or 8 waves on a 128x128 tile for launches with too few tiles to give every SIMD two waves)
 #ifndef FRX_OCC4W            // tuning aid: blocks per CU the four-wave tiles are compiled for (0: the table below)
 #define FRX_OCC4W 0
 #endif
-__global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1), SPEC ? 1 : (MODE == MODE_FWD3 || MODE == MODE_DGRAD3) ? ((BN == 64 && !(MODE == MODE_DGRAD3 && PRO == 2)) ? 3 : 2) : (NS > 4) ? (WM * WN) / 4 : (KC == 128 || PD > 3) ? 2 : (WM * WN == 8 ? 4 : (FRX_OCC4W ? FRX_OCC4W : ((PRO == 0 && EPI != EPI_BNBWD_OUT && !ADD) ? 3 : 2)))) void k_igemm(ConvArgs ka) {
+__global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1), SPEC ? 1 : (MODE == MODE_FWD3 || MODE == MODE_DGRAD3) ? ((BN == 64 && !(MODE == MODE_DGRAD3 && PRO == 2)) ? 3 : 2) : (NS > 4) ? (WM * WN) / 4 : (KC == 128 || PD > 3) ? 2 : (WM * WN == 8 ? 4 : (FRX_OCC4W ? FRX_OCC4W : (((PRO == 0 || (PRO == 3 && !PERSIST)) && EPI != EPI_BNBWD_OUT && !ADD) ? 3 : 2)))) void k_igemm(ConvArgs ka) {
   // P3 (MODE_FWD3 / MODE_DGRAD3): 3x3, stride 1, pad 1.  The rows a tile gathers over its nine taps are the CONTIGUOUS pixel
   // range [m0 - W - 1, m0 + BM + W + 1) of the flattened (n, h, w) axis, so per 64-byte channel chunk that range is staged
   // ONCE as a patch (LDS-DMA, then the BN prologue in place on the staging thread's own 16-byte pieces) and the nine taps
@@ -328,7 +370,8 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1), SPEC ? 1 : (MODE == 
   // 16-byte channel group sit next to each other, so one address register with immediate offsets reaches all of them,
   // as the fixed-size tables allowed.)
   extern __shared__ __attribute__((aligned(16))) float s_pro[];
-  constexpr int NTAB = PRO == 2 ? 3 : 2;
+  constexpr int NTAB = PRO >= 2 ? 3 : 2;
+  static_assert(PRO != 3 || (MODE == MODE_FWD && NS == 0), "the merge prologue: pointwise forward on the register ring");
 
   FRX_STAMP(0);
   constexpr bool STATS_ = (EPI == EPI_STATS || EPI == EPI_BNBWD || EPI == EPI_BNBWD_OUT);
@@ -408,15 +451,18 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1), SPEC ? 1 : (MODE == 
   // that walks the contraction axis, so the K loop spends no vector ALU on addresses, and an offset past
   // the end of the tensor returns zeros (padding taps and tile tails need no select).
   const __amdgpu_buffer_rsrc_t rsrcX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.X), 0, a.xbytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrcX2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(PRO == 2 ? a.X2 : a.X), 0, a.xbytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcX2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(PRO >= 2 ? a.X2 : a.X), 0, a.xbytes, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrcW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.W), 0, a.wbytes, 0x00020000);
   // PRO == 2 side output: the first column of tiles stores the transformed operand (dy).  The store is
   // unconditional (a branch in the K loop would cost the counted waits); every other block gets an EMPTY
   // descriptor, which drops the stores.
   // (patch mode: also the forward's transformed operand, relu(bn(x)), for the 3x3 weight gradient)
-  constexpr bool SIDE = PRO == 2 || (PRO == 1 && (MODE == MODE_FWD3 || MODE == MODE_DGRAD3));
+  constexpr bool SIDE = PRO == 2 || PRO == 3 || (PRO == 1 && (MODE == MODE_FWD3 || MODE == MODE_DGRAD3));
   const __amdgpu_buffer_rsrc_t rsrcDy = __builtin_amdgcn_make_buffer_rsrc(
       (SIDE && a.dy_out) ? a.dy_out : const_cast<void*>(a.X), 0, (SIDE && a.dy_out && nt == 0) ? a.xbytes : 0u, 0x00020000);
+  // (PRO == 3) the merge's > 0 bits, one byte per 16-byte channel group, by the same column of tiles
+  const __amdgpu_buffer_rsrc_t rsrcMask = __builtin_amdgcn_make_buffer_rsrc(
+      (PRO == 3 && a.mask_out) ? (void*)a.mask_out : const_cast<void*>(a.X), 0, (PRO == 3 && a.mask_out && nt == 0) ? a.xbytes / 16u : 0u, 0x00020000);
   constexpr unsigned OOB = 0x80000000u;
   unsigned bvoff[BLD];
 #pragma unroll
@@ -435,6 +481,24 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1), SPEC ? 1 : (MODE == 
           float* t = s_pro + (c / VEC) * (NTAB * VEC) + (c % VEC);
           t[0] = a.in_scale[c]; t[VEC] = a.in_shift[c];
           if constexpr (PRO == 2) t[2 * VEC] = a.pro_gam[c];
+          if constexpr (PRO == 3) { t[VEC] = a.id_scale ? a.id_scale[c] : 1.f; t[2 * VEC] = a.in_shift[c] + (a.id_shift ? a.id_shift[c] : 0.f); }
+        }
+      } else if constexpr (PRO == 3) {      // bn3's totals (and the projection BatchNorm's, if any) -> the merge's three constants
+        const BnTot b = bn_tot_copy(a.in_tot);
+        bn_tot_foreach<NT>(b.tot, b.R, a.Kc, [&](int c, double sm, double sq) {
+          float mean, invstd, sc, sh; double var;
+          bn_fwd_consts(sm, sq, b.inv_count, b.gamma[c], b.beta[c], b.eps, mean, invstd, sc, sh, var);
+          float* t = s_pro + (c / VEC) * (NTAB * VEC) + (c % VEC);
+          t[0] = sc; t[VEC] = 1.f; t[2 * VEC] = sh + 0.f;
+        });
+        if (a.id_tot.tot) {      // (the same thread owns channel c in both passes: no barrier in between)
+          const BnTot bd = bn_tot_copy(a.id_tot);
+          bn_tot_foreach<NT>(bd.tot, bd.R, a.Kc, [&](int c, double sm, double sq) {
+            float mean, invstd, sc, sh; double var;
+            bn_fwd_consts(sm, sq, bd.inv_count, bd.gamma[c], bd.beta[c], bd.eps, mean, invstd, sc, sh, var);
+            float* t = s_pro + (c / VEC) * (NTAB * VEC) + (c % VEC);
+            t[VEC] = sc; t[2 * VEC] = t[2 * VEC] + sh;
+          });
         }
       } else if constexpr (PRO == 1) {      // the producer's replicated totals -> scale / shift (bn_tot.h)
         const BnTot b = bn_tot_copy(a.in_tot);
@@ -461,7 +525,7 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1), SPEC ? 1 : (MODE == 
   // so loads run PD-1 chunks ahead of the LDS write that consumes them.
   constexpr int RD = DMA ? 1 : PD;
   uint4 ra[RD][ALD], rb[RD][BLD];
-  uint4 ra2[PRO == 2 ? PD : 1][ALD];   // second gathered tensor (PRO == 2)
+  uint4 ra2[PRO >= 2 ? PD : 1][ALD];   // second gathered tensor (PRO == 2: raw y; PRO == 3: the identity)
   int rc0[RD];                  // channel offset each ring slot was loaded at (for the BN prologue)
   unsigned rmask[RD];           // which of the slot's A rows were in bounds (padding stays exactly 0)
   unsigned avoff[ALD];          // byte offset of the gathered pixel of the CURRENT tap (OOB when out of bounds)
@@ -505,7 +569,7 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1), SPEC ? 1 : (MODE == 
 #pragma unroll
     for (int i = 0; i < ALD; ++i) {
       ra[slot][i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rsrcX, avoff[i], so, 0));
-      if constexpr (PRO == 2) ra2[slot][i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rsrcX2, avoff[i], so, 0));
+      if constexpr (PRO >= 2) ra2[slot][i] = as_uint4(__builtin_amdgcn_raw_buffer_load_b128(rsrcX2, avoff[i], so, 0));
       m |= (aok[i] ? 1u : 0u) << i;
     }
     rmask[slot] = m;
@@ -554,12 +618,19 @@ __global__ __launch_bounds__(64 * WM * WN * (SPEC ? 2 : 1), SPEC ? 1 : (MODE == 
       if constexpr (PRO == 2)
         v = affine2_vec<T>(v, ra2[slot][i], s_pro + (rc0[slot] + chunk * VEC) * NTAB, s_pro + (rc0[slot] + chunk * VEC) * NTAB + VEC,
                            s_pro + (rc0[slot] + chunk * VEC) * NTAB + 2 * VEC);
+      unsigned mbits = 0;
+      if constexpr (PRO == 3) {
+        const float* tb = s_pro + (rc0[slot] + chunk * VEC) * NTAB;
+        v = merge_vec<T>(v, ra2[slot][i], tb, tb + VEC, tb + 2 * VEC, mbits);
+      }
       if constexpr (PRO != 0) {      // out-of-range loads are already 0; a prologue would turn them into f(0)
         if (!((rmask[slot] >> i) & 1u)) v = make_uint4(0, 0, 0, 0);
       }
-      if constexpr (PRO == 2) {      // (soffset stays the literal 0: see the note on stores in the epilogue)
+      if constexpr (PRO == 2 || PRO == 3) {      // (soffset stays the literal 0: see the note on stores in the epilogue)
         u32x4_t sv; sv[0] = v.x; sv[1] = v.y; sv[2] = v.z; sv[3] = v.w;
-        __builtin_amdgcn_raw_buffer_store_b128(sv, rsrcDy, avoff[i] + (unsigned)(rc0[slot] * (int)sizeof(T)), 0, 0);
+        const unsigned so_b = avoff[i] + (unsigned)(rc0[slot] * (int)sizeof(T));
+        __builtin_amdgcn_raw_buffer_store_b128(sv, rsrcDy, so_b, 0, 0);
+        if constexpr (PRO == 3) __builtin_amdgcn_raw_buffer_store_b8((unsigned char)mbits, rsrcMask, so_b >> 4, 0, 0);   // (rows past M: offset past the descriptor)
       }
       const int row = srow + RPP * i;
       *reinterpret_cast<uint4*>(As + (row * CPR + (chunk ^ swz_row<KC>(row))) * 16) = v;

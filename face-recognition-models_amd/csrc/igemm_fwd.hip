@@ -1,7 +1,9 @@
 // k_igemm instantiations: forward (and fc) and the stem.
 #include "conv_launch.h"
 namespace frx {
+int launch_igemm_fwd_merge(hipStream_t st, const ConvArgs& a, int dtype, TileCfg c, int grid, int epi);      // igemm_fwd_merge.hip
 int launch_igemm_fwd(hipStream_t st, const ConvArgs& a, int dtype, TileCfg c, int grid, int pro, int epi) {
+  if (pro == 3) return launch_igemm_fwd_merge(st, a, dtype, c, grid, epi);
   if (pro == 1) {
     if (epi == EPI_STATS) FRX_IGEMM_DT(MODE_FWD, 1, EPI_STATS, false);
     else if (epi == EPI_PLAIN) FRX_IGEMM_DT(MODE_FWD, 1, EPI_PLAIN, false);

@@ -74,6 +74,8 @@ _SIGS = {
     "frx_stem_padded_dims": (C.c_int, [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "frx_conv_fwd": (C.c_int, [C.c_int, _P, C.POINTER(ConvDesc), _P, _P, _P, _P, C.c_int, _P, _P, C.c_int, _P]),
     "frx_conv_fwd_tot": (C.c_int, [C.c_int, _P, C.POINTER(ConvDesc), _P, _P, C.POINTER(BnTot), C.c_int, _P, _P, C.c_int]),
+    "frx_conv_fwd_merge": (C.c_int, [C.c_int, _P, C.POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, C.POINTER(BnTot), C.POINTER(BnTot),
+                                     _P, _P, _P, _P, _P, C.c_int]),
     "frx_conv_fwd_keep": (C.c_int, [C.c_int, _P, C.POINTER(ConvDesc), _P, _P, _P, _P, C.POINTER(BnTot), C.c_int, _P, _P, _P, C.c_int, _P]),
     "frx_block_merge_fwd_tot": (C.c_int, [C.c_int, _P, C.c_int, C.c_int64, C.c_int, _P, C.POINTER(BnTot), _P, C.POINTER(BnTot), _P, _P]),
     "frx_bn_finalize_batched": (C.c_int, [C.c_int, _P, C.c_int, _P, C.c_int]),

@@ -221,6 +221,7 @@ class ResNet50Engine:
         self.fused_bn = (dtype == BF16 and self.grouped_wgrad and os.environ.get("FRX_BN_DETERMINISTIC", "0") != "1")
         if self.fused_bn:
             self._plan_bn_totals()
+        self.merge_fuse = os.environ.get("FRX_MERGE_FUSE", "1")
         self.fused_stem_bwd = True         # (False: max-pool backward + stand-alone BN backward, the form the fused stem kernels are tested against)
         self.mask_bits = True              # (False: the backward re-reads the block output instead of its 1-bit mask)
         self._wg_groups = None                               # planned at the end of __init__ (needs every buffer)
@@ -442,6 +443,16 @@ class ResNet50Engine:
             ops.conv_fwd(c.desc, x, c.wk, c.y, **kw)
         return c.y
 
+    def _merge_fused(self, b):
+        """whether block b's residual merge runs as the prologue of the next block's conv1 (replicated-totals training
+        forward; FRX_MERGE_FUSE: "0" never, "all" wherever the next block has no projection, or the layers it pays in, e.g.
+        "12" -- measured per layer inside a training step)"""
+        sel = self.merge_fuse
+        if sel == "0":
+            return False
+        layer = PLANES.index(b.conv1.Co) + 1
+        return sel == "all" or str(layer) in sel
+
     def _prepare_eval_affine(self):
         for c in self.convs:
             ops.bn_eval_affine(self.gamma(c), self.beta(c), self._bn(self.running_mean, c),
@@ -483,16 +494,37 @@ class ResNet50Engine:
                               self.pool_out, self.pool_arg)
         x = self.pool_out
         side = self.branch_stream if fused else None
-        for b in self.blocks:
+        pending = None                  # (block, its input): a merge deferred into the next block's conv1 (frx_conv_fwd_merge)
+        for bi, b in enumerate(self.blocks):
             if side is not None and b.down is not None:      # projection next to the chain
                 side.wait_stream(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(side):
                     self._conv_bn(b.down, x, None)
-            self._conv_bn(b.conv1, x, None)
+            if pending is not None:
+                # the block before's out = relu(bn3(y3) + identity) is evaluated in this conv1's prologue and stored once on the
+                # way (its merge pass: a read of the block output and a launch less per block)
+                pb, px = pending
+                pending = None
+                if pb.down is not None and side is not None:
+                    torch.cuda.current_stream(self.device).wait_stream(side)
+                c1 = b.conv1
+                ops.conv_fwd_merge(c1.desc, pb.conv3.y, pb.down.y if pb.down is not None else px, c1.wk, c1.y, pb.out,
+                                   mask=pb.mask if self.mask_bits else None, bn3=pb.conv3.tot_f,
+                                   bnd=pb.down.tot_f if pb.down is not None else None,
+                                   stat_totals=c1.tot_f_buf, stat_replicas=c1.R)
+            else:
+                self._conv_bn(b.conv1, x, None)
             self._conv_bn(b.conv2, b.conv1.y, b.conv1)
             self._conv_bn(b.conv3, b.conv2.y, b.conv2)
             rows = b.out.numel() // b.conv3.Co
             if fused:
+                nxt = self.blocks[bi + 1] if bi + 1 < len(self.blocks) else None
+                if nxt is not None and nxt.down is None and self._merge_fused(b):
+                    if b.down is not None and side is None:
+                        self._conv_bn(b.down, x, None)
+                    pending = (b, x)          # nothing reads b.out before the next conv1 has stored it
+                    x = b.out
+                    continue
                 if b.down is not None:
                     if side is not None:
                         torch.cuda.current_stream(self.device).wait_stream(side)

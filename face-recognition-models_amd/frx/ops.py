@@ -33,7 +33,7 @@ def _timed(label, flops, dev_tensor, fn, nbytes=0):
 
 
 _MODE = {0: "fwd", 1: "dgrad", 2: "stem", 3: "fwd3x3patch", 4: "dgrad3x3patch"}
-_PRO = {0: "none", 1: "bn_relu", 2: "bn_bwd"}
+_PRO = {0: "none", 1: "bn_relu", 2: "bn_bwd", 3: "merge"}
 _EPI = {0: "plain", 1: "stats", 2: "bnbwd_stats", 3: "fc", 4: "bnbwd_stats_maskout"}
 
 
@@ -357,6 +357,18 @@ def conv_fwd_tot(d, x, w, y, in_bn=None, in_relu=True, stat_totals=None, stat_re
         _lib.lib().frx_conv_fwd_tot(_dev(x), _stream(x), C.byref(d), _p(x), _p(w), C.byref(in_bn) if in_bn is not None else None,
                                     int(in_relu), _p(y), _p(stat_totals), int(stat_replicas)), "frx_conv_fwd_tot"),
         nbytes=conv_bytes(d))
+    return y
+
+
+def conv_fwd_merge(d, y3, idn, w, y, block_out, mask=None, s3=None, b3=None, sd=None, bd=None, bn3=None, bnd=None,
+                   stat_partial=None, stat_totals=None, stat_replicas=0):
+    """frx_conv_fwd_merge: a 1x1 conv on relu(bn3(y3) + idn') with the merge evaluated as its prologue; block_out / mask
+    receive what frx_block_merge_fwd* would have written.  BatchNorm constants as arrays (s3, b3[, sd, bd]) or totals."""
+    _timed(_igemm_label(d.dtype), conv_flops(d), y3, lambda: check(
+        _lib.lib().frx_conv_fwd_merge(_dev(y3), _stream(y3), C.byref(d), _p(y3), _p(idn), _p(w), _p(s3), _p(b3), _p(sd), _p(bd),
+                                      C.byref(bn3) if bn3 is not None else None, C.byref(bnd) if bnd is not None else None,
+                                      _p(block_out), _p(mask), _p(y), _p(stat_partial), _p(stat_totals), int(stat_replicas)),
+        "frx_conv_fwd_merge"), nbytes=conv_bytes(d, n_in=3) + (0 if mask is None else mask.numel()))
     return y
 
 

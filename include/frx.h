@@ -228,6 +228,18 @@ typedef struct frx_bn_tot {
   float eps;             /* forward */
   int32_t reserved;
 } frx_bn_tot;
+/* A 1x1 / stride-1 convolution whose input is the residual merge of the block BEFORE it, evaluated as the prologue:
+ *   x = relu(s3 * y3 + b3 + (sd * idn + bd))      (sd = 1, bd = 0 when sd == NULL: a plain identity)
+ * i.e. torchvision Bottleneck.forward's `out = bn3(conv3(..)); out += identity; out = relu(out)` (backbones.py:16-18)
+ * feeding the next Bottleneck's conv1, without the pass over memory frx_block_merge_fwd* spends on it.  y3 / idn [M, Ci]
+ * are the previous block's raw conv3 output and its identity (the block input, or the raw output of its projection);
+ * the BatchNorm constants come as arrays (s3, b3[, sd, bd]) or as replicated totals (bn3[, bnd]) -- one form for both.
+ * block_out [M, Ci] receives x (what the merge pass would have written, bit for bit) and mask [M * Ci / V] its > 0 bits
+ * (may be NULL), both stored once by the first column of tiles; y and the statistics are frx_conv_fwd's / _tot's. */
+int frx_conv_fwd_merge(int device, frx_stream_t stream, const frx_conv_desc* d, const void* y3, const void* idn,
+                       const void* w, const float* s3, const float* b3, const float* sd, const float* bd,
+                       const frx_bn_tot* bn3, const frx_bn_tot* bnd, void* block_out, uint8_t* mask, void* y,
+                       float* stat_partial, float* stat_totals, int stat_replicas);
 /* frx_conv_fwd with the prologue constants taken from `in_bn` (NULL: no prologue) and the statistics of y ADDED into
  * stat_totals [stat_replicas][2][Co] (NULL: none) */
 int frx_conv_fwd_tot(int device, frx_stream_t stream, const frx_conv_desc* d, const void* x, const void* w_krsc,

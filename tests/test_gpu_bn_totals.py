@@ -246,6 +246,61 @@ def test_conv_fwd_tot_equals_conv_fwd(dtype, shape, monkeypatch):
 
 @pytest.mark.parametrize("dtype", [0, 1], ids=["f32", "bf16"])
 @pytest.mark.parametrize("down", [False, True], ids=["identity", "projection"])
+@pytest.mark.parametrize("form", ["arrays", "totals"])
+@pytest.mark.parametrize("shape", [(256, 64, 28, 8), (512, 128, 14, 16), (1024, 256, 7, 32), (2048, 512, 4, 20), (128, 64, 5, 3), (64, 192, 9, 2)],
+                         ids=lambda s: "x".join(map(str, s)))
+def test_conv_fwd_merge_equals_merge_then_conv(dtype, down, form, shape):
+    """frx_conv_fwd_merge (the residual merge of the block before as the prologue of the next conv1; round 4) against the
+    two launches it replaces on the same inputs: block output and mask bits as frx_block_merge_fwd(_mask / _tot) writes them,
+    BIT FOR BIT; the conv output bit for bit (same tile, same K order, the staged operand is the same bf16 / fp32 values);
+    the statistics to float-sum rounding.  ResNet-50's conv1 shapes of the four layers plus ragged ones (75 and 162 pixel
+    rows: tile tails; 192 output columns: the 64-column tile)."""
+    from frx import ops
+    Ci, Co, H, N = shape
+    R, count = 8, N * H * H
+    rows = N * H * H
+    g = torch.Generator().manual_seed(Ci + Co + H)
+
+    def tot(C_):
+        t = torch.zeros(R, 2, C_, device=DEV)
+        t[:, 0] = (torch.randn(R, C_, generator=g) * 10).to(DEV); t[:, 1] = (torch.rand(R, C_, generator=g) * 300 + 100).to(DEV)
+        ga, be = (torch.rand(C_, generator=g) + 0.5).to(DEV), (torch.randn(C_, generator=g) * 0.3).to(DEV)
+        ga[::5] *= -1
+        return t, ga, be
+    t3, g3, b3 = tot(Ci); td, gd, bd = tot(Ci)
+    _, _, s3, h3 = _fwd_consts(t3, count, g3, b3)
+    _, _, sd, hd = _fwd_consts(td, count, gd, bd)
+    y3, idn = _rand(dtype, N, H, H, Ci, seed=1), _rand(dtype, N, H, H, Ci, seed=2)
+    w = _rand(dtype, Co, 1, 1, Ci, seed=3, scale=Ci ** -0.5)
+    V = 8 if dtype == 1 else 4
+    d = ops.conv_desc(dtype, N, H, H, Ci, Co, 1, 1, 1, 0)
+    # the two launches
+    o0 = torch.empty_like(y3); m0 = torch.zeros(rows * Ci // V, dtype=torch.uint8, device=DEV)
+    ops.block_merge_fwd(dtype, rows, Ci, y3, s3, h3, idn, o0, sd=sd if down else None, bd=hd if down else None, mask=m0)
+    y0 = torch.empty(N, H, H, Co, dtype=y3.dtype, device=DEV)
+    tout0 = torch.zeros(R, 2, Co, device=DEV)
+    ops.conv_fwd_tot(d, o0, w, y0, in_bn=None, stat_totals=tout0, stat_replicas=R)
+    # the fused launch
+    o1 = torch.full_like(y3, 7.0); m1 = torch.full_like(m0, 255)
+    y1 = torch.empty_like(y0); tout1 = torch.zeros_like(tout0)
+    if form == "arrays":
+        kw = dict(s3=s3, b3=h3, sd=sd if down else None, bd=hd if down else None)
+    else:
+        kw = dict(bn3=ops.bn_tot(t3, R, count, g3, beta=b3), bnd=ops.bn_tot(td, R, count, gd, beta=bd) if down else None)
+    ops.conv_fwd_merge(d, y3, idn, w, y1, o1, mask=m1, stat_totals=tout1, stat_replicas=R, **kw)
+    assert torch.equal(o1, o0), "block output: the merge pass's bits"
+    assert torch.equal(m1, m0), "mask bits"
+    assert torch.equal(y1, y0), "conv output"
+    a, b = tout1.sum(0), tout0.sum(0)
+    assert (a - b).abs().max().item() <= 2e-5 * b.abs().max().item() + 1e-6
+    # plain epilogue (no statistics), no mask
+    y2 = torch.empty_like(y0); o2 = torch.empty_like(y3)
+    ops.conv_fwd_merge(d, y3, idn, w, y2, o2, **kw)
+    assert torch.equal(y2, y0) and torch.equal(o2, o0)
+
+
+@pytest.mark.parametrize("dtype", [0, 1], ids=["f32", "bf16"])
+@pytest.mark.parametrize("down", [False, True], ids=["identity", "projection"])
 def test_merge_and_pool_tot_equal_their_twins(dtype, down):
     from frx import ops
     rows, Cc, R, count = 37 * 49, 256, 8, 1813
