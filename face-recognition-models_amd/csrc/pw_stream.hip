@@ -275,7 +275,7 @@ bool pw_stream_ok(const ConvArgs& a, int dtype, int epi) {
   const bool pw = a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0 && !a.s2c;
   if (dtype != FRX_BF16 || !pw || !a.stat_tot || a.stat_partial || a.out_f32 || a.bias || a.addend) return false;
   if (a.mode == MODE_FWD && a.X2)      // the merge prologue (frx_conv_fwd_merge): layer1's shape
-    return a.dy_out && epi == EPI_STATS && a.Kc == 256 && a.Ncol == 64;
+    return a.dy_out && epi == EPI_STATS && a.Kc == 256 && (a.Ncol == 64 || a.Ncol == 128);      // layer1's conv1 and layer2's first conv1
   if (a.dy_out) return false;
   if (a.mode == MODE_FWD) return !a.in_scale && !a.in_tot.tot && epi == EPI_STATS && shape_ok(a.Kc, a.Ncol, false);
   if (a.mode == MODE_DGRAD) return a.X2 && epi == EPI_BNBWD && a.e_scale && a.e_shift && !a.e_out && !a.e_bits && shape_ok(a.Kc, a.Ncol, true);
@@ -303,7 +303,7 @@ static void launch_one(hipStream_t st, const ConvArgs& a) {
 int launch_pw_stream(hipStream_t st, const ConvArgs& a) {
   const bool dg = a.mode == MODE_DGRAD, mg = a.mode == MODE_FWD && a.X2;
   note_igemm_launch(16, a.Ncol, 8, 64, 0, a.mode, dg ? 2 : (mg ? 3 : 0), dg ? EPI_BNBWD : EPI_STATS, 0, 1, 3);
-  if (mg) launch_one<256, 64, PWS_MERGE>(st, a);
+  if (mg) { if (a.Ncol == 64) launch_one<256, 64, PWS_MERGE>(st, a); else launch_one<256, 128, PWS_MERGE>(st, a); }
   else if (a.Kc == 256 && a.Ncol == 64) { if (dg) launch_one<256, 64, PWS_DGRAD>(st, a); else launch_one<256, 64, PWS_FWD>(st, a); }
   else if (a.Kc == 512 && a.Ncol == 128) { if (dg) launch_one<512, 128, PWS_DGRAD>(st, a); else launch_one<512, 128, PWS_FWD>(st, a); }
   else launch_one<256, 128, PWS_FWD>(st, a);

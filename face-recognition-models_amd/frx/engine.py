@@ -453,6 +453,13 @@ class ResNet50Engine:
         layer = PLANES.index(b.conv1.Co) + 1
         return sel == "all" or str(layer) in sel
 
+    def _merge_into_first(self, nxt):
+        """a layer's first block: its conv1 takes the merge of the layer before as a prologue where the streamed kernel serves the
+        shape (layer2's 256 -> 128: the largest merge of the network, 103 MB at batch 256); the block's projection then reads
+        the stored block output behind it.  FRX_MERGE_FIRST=0: off"""
+        c = nxt.conv1
+        return (self.dtype == ops.BF16 and c.Ci == 256 and c.Co == 128 and os.environ.get("FRX_MERGE_FIRST", "1") != "0")
+
     def _prepare_eval_affine(self):
         for c in self.convs:
             ops.bn_eval_affine(self.gamma(c), self.beta(c), self._bn(self.running_mean, c),
@@ -496,10 +503,12 @@ class ResNet50Engine:
         side = self.branch_stream if fused else None
         pending = None                  # (block, its input): a merge deferred into the next block's conv1 (frx_conv_fwd_merge)
         for bi, b in enumerate(self.blocks):
-            if side is not None and b.down is not None:      # projection next to the chain
+            proj_launched = False           # this block's projection (in line it waits until its output is needed)
+            if side is not None and b.down is not None and pending is None:      # projection next to the chain
                 side.wait_stream(torch.cuda.current_stream(self.device))
                 with torch.cuda.stream(side):
                     self._conv_bn(b.down, x, None)
+                proj_launched = True
             if pending is not None:
                 # the block before's out = relu(bn3(y3) + identity) is evaluated in this conv1's prologue and stored once on the
                 # way (its merge pass: a read of the block output and a launch less per block)
@@ -512,6 +521,14 @@ class ResNet50Engine:
                                    mask=pb.mask if self.mask_bits else None, bn3=pb.conv3.tot_f,
                                    bnd=pb.down.tot_f if pb.down is not None else None,
                                    stat_totals=c1.tot_f_buf, stat_replicas=c1.R)
+                if b.down is not None:      # this block's projection reads the block output the launch above has just stored
+                    if side is not None:
+                        side.wait_stream(torch.cuda.current_stream(self.device))
+                        with torch.cuda.stream(side):
+                            self._conv_bn(b.down, x, None)
+                    else:
+                        self._conv_bn(b.down, x, None)
+                    proj_launched = True
             else:
                 self._conv_bn(b.conv1, x, None)
             self._conv_bn(b.conv2, b.conv1.y, b.conv1)
@@ -519,17 +536,17 @@ class ResNet50Engine:
             rows = b.out.numel() // b.conv3.Co
             if fused:
                 nxt = self.blocks[bi + 1] if bi + 1 < len(self.blocks) else None
-                if nxt is not None and nxt.down is None and self._merge_fused(b):
-                    if b.down is not None and side is None:
+                if nxt is not None and (nxt.down is None or self._merge_into_first(nxt)) and self._merge_fused(b):
+                    if b.down is not None and not proj_launched:
                         self._conv_bn(b.down, x, None)
                     pending = (b, x)          # nothing reads b.out before the next conv1 has stored it
                     x = b.out
                     continue
                 if b.down is not None:
-                    if side is not None:
-                        torch.cuda.current_stream(self.device).wait_stream(side)
-                    else:
+                    if not proj_launched:
                         self._conv_bn(b.down, x, None)
+                    elif side is not None:
+                        torch.cuda.current_stream(self.device).wait_stream(side)
                 ops.block_merge_fwd_tot(dt, rows, b.conv3.Co, b.conv3.y, b.conv3.tot_f, b.down.y if b.down is not None else x,
                                         b.out, bnd=b.down.tot_f if b.down is not None else None,
                                         mask=b.mask if self.mask_bits else None)

@@ -247,7 +247,7 @@ def test_conv_fwd_tot_equals_conv_fwd(dtype, shape, monkeypatch):
 @pytest.mark.parametrize("dtype", [0, 1], ids=["f32", "bf16"])
 @pytest.mark.parametrize("down", [False, True], ids=["identity", "projection"])
 @pytest.mark.parametrize("form", ["arrays", "totals"])
-@pytest.mark.parametrize("shape", [(256, 64, 28, 8), (512, 128, 14, 16), (1024, 256, 7, 32), (2048, 512, 4, 20), (128, 64, 5, 3), (64, 192, 9, 2)],
+@pytest.mark.parametrize("shape", [(256, 64, 28, 8), (256, 128, 28, 5), (512, 128, 14, 16), (1024, 256, 7, 32), (2048, 512, 4, 20), (128, 64, 5, 3), (64, 192, 9, 2)],
                          ids=lambda s: "x".join(map(str, s)))
 def test_conv_fwd_merge_equals_merge_then_conv(dtype, down, form, shape):
     """frx_conv_fwd_merge (the residual merge of the block before as the prologue of the next conv1; round 4) against the
