@@ -22,7 +22,7 @@ def timed(label, flops, t, fn, nbytes=0):
     cur[0] = None
     return orig(label, flops, t, fn, nbytes)
 ops._timed = timed
-for name in ("conv_fwd", "conv_fwd_tot", "conv_fwd_keep", "conv_dgrad", "conv_wgrad", "conv_dgrad_bn", "conv_wgrad_bn"):
+for name in ("conv_fwd", "conv_fwd_tot", "conv_fwd_keep", "conv_fwd_merge", "conv_dgrad", "conv_wgrad", "conv_dgrad_bn", "conv_wgrad_bn"):
     f = getattr(ops, name)
     def mk(f, name):
         def w(d, *a, **k):
